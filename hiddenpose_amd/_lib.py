@@ -1,0 +1,74 @@
+"""ctypes binding of libhiddenpose_hip.so (C ABI: include/hiddenpose_hip.h).
+
+The library is REQUIRED: there is no eager/CPU fallback anywhere in this package.
+`lib()` raises if the shared object has not been built (python -m hiddenpose_amd.build).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libhiddenpose_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class HiddenPoseHipError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol declared in include/hiddenpose_hip.h
+_vp, _fp, _i, _sz, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_double
+SIGNATURES = {
+    "hp_version": (_i, []),
+    "hp_last_error_string": (C.c_char_p, []),
+    "hp_lct_host_constants": (_i, [_i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hp_lct_plan_create": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i]),
+    "hp_lct_plan_destroy": (_i, [_vp]),
+    "hp_lct_workspace_bytes": (_sz, [_vp, _i]),
+    "hp_lct_forward": (_i, [_vp, _fp, _fp, _i, _vp, _sz, _vp]),
+    "hp_lct_backward": (_i, [_vp, _fp, _fp, _i, _vp, _sz, _vp]),
+    "hp_lct_plan_get_invpsf": (_i, [_vp, _vp, _vp]),
+}
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HiddenPoseHipError(
+                        f"{LIB_PATH} is missing: the HIP extension is required (no fallback path). "
+                        "Build it with `python -m hiddenpose_amd.build`.")
+                dll = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(dll, name)  # AttributeError here = header/library mismatch
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = dll
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().hp_last_error_string()
+        raise HiddenPoseHipError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Raw device/host address of a contiguous torch tensor or numpy array (0 for None)."""
+    if t is None:
+        return 0
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def current_stream_handle(device=None) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,676 @@
+// LCT physics layer on gfx950: plan + forward/backward.
+//
+// Reference operator (models/feature_propagation.py:186-257):
+//   y = mtx^T . crop( Re F3^-1( invpsf . F3( pad( mtx . (g^4 . x) ) ) ) )
+// with F3 a (2T,2N,2N) FFT of the (T,N,N) volume zero-padded at the high end.
+//
+// MI355X formulation (HBM-bound, everything fp32):
+//  * two real volumes of a batch are packed as ONE complex volume (re = sample
+//    2p, im = sample 2p+1).  invpsf is Hermitian, so the padded Wiener filter is a
+//    real-linear operator and the two results come back as Re / Im.  No
+//    real-to-complex symmetry code, no wasted half spectrum.
+//  * a zero-padded 2L-point DFT splits into two L-point DFTs (even bins: the
+//    data itself; odd bins: the data times e^{-i pi n/L}); symmetrically the first
+//    L outputs of the inverse are the sum of two L-point inverse DFTs.  Every pass
+//    therefore works on L-point transforms and the padding is never stored.
+//  * forward passes are decimation-in-frequency (natural in, digit-reversed
+//    out), inverse passes decimation-in-time (digit-reversed in, natural out), so
+//    no reordering pass exists: invpsf is stored once in the matching permuted
+//    order, pre-scaled by 1/(8 T N N).
+//  * pass order T -> H -> [W . filter . W^-1] -> H^-1 -> T^-1.  The t-resampling
+//    band operators (and g^4) are fused into the first and last pass, the filter
+//    into the middle one; the heaviest pass (filter) streams contiguous rows.
+//  * backward = the same pipeline with conj(invpsf) and the two band operators
+//    swapped (adjoint; mtxi = mtx^T).
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "hp_internal.h"
+#include "lct_host.h"
+
+namespace hp {
+
+constexpr int NT = 256;  // threads per workgroup (4 waves of 64)
+
+struct BandDev {
+  int32_t* off = nullptr;
+  int32_t* idx = nullptr;
+  float* val = nullptr;
+};
+
+}  // namespace hp
+
+struct hp_lct_plan {
+  int T = 0, N = 0, material = 0, device = 0;
+  hp::LctHost host;
+  std::vector<int> permT, permN;  // array position along a doubled axis -> natural frequency
+  float2* Hdev = nullptr;         // [2T][2N][2N] permuted, scaled
+  float2 *twT = nullptr, *hsT = nullptr, *twN = nullptr, *hsN = nullptr;
+  hp::BandDev fwd_in, fwd_out, bwd_in, bwd_out;
+};
+
+namespace hp {
+
+// ---------------------------------------------------------------- device FFT
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// L-point transforms along dim 0 of an LDS tile s[L][LD] for columns 0..WT-1.
+// tw[p] = exp(-2 pi i p / L).  Forward: DIF, natural in -> digit-reversed out.
+template <int L, int WT, int LD>
+__device__ __forceinline__ void fft_dif(float2* s, const float2* tw, int tid) {
+#pragma unroll
+  for (int n = L; n >= 4; n >>= 2) {
+    const int m = n >> 2;
+    const int tstep = L / n;
+    for (int b = tid; b < (L / 4) * WT; b += NT) {
+      const int col = b % WT, bf = b / WT;
+      const int j = bf % m, blk = bf / m;
+      float2* p = s + (blk * n + j) * LD + col;
+      float2 a0 = p[0], a1 = p[m * LD], a2 = p[2 * m * LD], a3 = p[3 * m * LD];
+      float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+      float2 t3 = make_float2(d.y, -d.x);  // -i * (a1 - a3)
+      float2 y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+      if (m > 1) {
+        y1 = cmul(y1, tw[tstep * j]);
+        y2 = cmul(y2, tw[tstep * 2 * j]);
+        y3 = cmul(y3, tw[tstep * 3 * j]);
+      }
+      p[0] = y0;
+      p[m * LD] = y1;
+      p[2 * m * LD] = y2;
+      p[3 * m * LD] = y3;
+    }
+    __syncthreads();
+  }
+  if constexpr ((L & 0x55555555) == 0) {  // odd log2: final radix-2 stage on adjacent pairs
+    for (int b = tid; b < (L / 2) * WT; b += NT) {
+      const int col = b % WT, blk = b / WT;
+      float2* p = s + (blk * 2) * LD + col;
+      float2 a0 = p[0], a1 = p[LD];
+      p[0] = cadd(a0, a1);
+      p[LD] = csub(a0, a1);
+    }
+    __syncthreads();
+  }
+}
+
+// Inverse (unnormalised): DIT, digit-reversed in -> natural out; exact mirror of fft_dif.
+template <int L, int WT, int LD>
+__device__ __forceinline__ void fft_dit(float2* s, const float2* tw, int tid) {
+  if constexpr ((L & 0x55555555) == 0) {
+    for (int b = tid; b < (L / 2) * WT; b += NT) {
+      const int col = b % WT, blk = b / WT;
+      float2* p = s + (blk * 2) * LD + col;
+      float2 a0 = p[0], a1 = p[LD];
+      p[0] = cadd(a0, a1);
+      p[LD] = csub(a0, a1);
+    }
+    __syncthreads();
+  }
+  constexpr int n0 = ((L & 0x55555555) == 0) ? 8 : 4;
+#pragma unroll
+  for (int n = n0; n <= L; n <<= 2) {
+    const int m = n >> 2;
+    const int tstep = L / n;
+    for (int b = tid; b < (L / 4) * WT; b += NT) {
+      const int col = b % WT, bf = b / WT;
+      const int j = bf % m, blk = bf / m;
+      float2* p = s + (blk * n + j) * LD + col;
+      float2 a0 = p[0], a1 = p[m * LD], a2 = p[2 * m * LD], a3 = p[3 * m * LD];
+      if (m > 1) {
+        a1 = cmulc(a1, tw[tstep * j]);
+        a2 = cmulc(a2, tw[tstep * 2 * j]);
+        a3 = cmulc(a3, tw[tstep * 3 * j]);
+      }
+      float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+      float2 t3 = make_float2(-d.y, d.x);  // +i * (a1 - a3)
+      p[0] = cadd(t0, t2);
+      p[m * LD] = cadd(t1, t3);
+      p[2 * m * LD] = csub(t0, t2);
+      p[3 * m * LD] = csub(t1, t3);
+    }
+    __syncthreads();
+  }
+}
+
+struct PassGeom {
+  long in_pair_stride, out_pair_stride;    // elements per packed pair
+  int chunks_per_outer;                    // tiles per outer index
+  long in_outer_stride, out_outer_stride;  // elements
+  long in_axis_stride, out_axis_stride;    // elements between consecutive axis samples
+};
+
+// Forward pass along one axis: L samples in, 2L (parity q, position) out.
+// REAL_IN: input is the real batch (B,T,N,N); samples 2p / 2p+1 become re / im and the
+// band operator (t-resampling, fused g^k scaling) is applied on the way in.
+template <int L, int WT, bool REAL_IN>
+__global__ __launch_bounds__(NT) void k_axis_fwd(const float* __restrict__ xr, const float2* __restrict__ in,
+                                                 float2* __restrict__ out, int batch, long vol, PassGeom g,
+                                                 const float2* __restrict__ tw, const float2* __restrict__ hs,
+                                                 const int32_t* __restrict__ boff, const int32_t* __restrict__ bidx,
+                                                 const float* __restrict__ bval) {
+  constexpr int EPT = (L * WT) / NT;
+  static_assert(EPT >= 1 && (L * WT) % NT == 0, "tile must cover the workgroup");
+  __shared__ float2 s[L * WT];
+  __shared__ float2 stw[L];
+  __shared__ float2 shs[L];
+  const int tid = threadIdx.x;
+  const int pair = blockIdx.z;
+  const int outer = blockIdx.x / g.chunks_per_outer, chunk = blockIdx.x % g.chunks_per_outer;
+  const long ibase = (long)outer * g.in_outer_stride + (long)chunk * WT;
+  const long obase = (long)pair * g.out_pair_stride + (long)outer * g.out_outer_stride + (long)chunk * WT;
+  for (int i = tid; i < L; i += NT) {
+    stw[i] = tw[i];
+    shs[i] = hs[i];
+  }
+  float2 u[EPT];
+  if constexpr (REAL_IN) {
+    const float* x0 = xr + (long)(2 * pair) * vol;
+    const bool has1 = (2 * pair + 1) < batch;
+    const float* x1 = xr + (long)(2 * pair + 1) * vol;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      const long gi = ibase + (long)n * g.in_axis_stride + col;
+      s[e] = make_float2(x0[gi], has1 ? x1[gi] : 0.0f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      float2 acc = make_float2(0.f, 0.f);
+      for (int t = boff[n]; t < boff[n + 1]; ++t) {
+        const float c = bval[t];
+        const float2 v = s[bidx[t] * WT + col];
+        acc.x += c * v.x;
+        acc.y += c * v.y;
+      }
+      u[k] = acc;
+    }
+  } else {
+    const float2* ip = in + (long)pair * g.in_pair_stride;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      u[k] = ip[ibase + (long)n * g.in_axis_stride + col];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT;
+      s[e] = q ? cmul(u[k], shs[n]) : u[k];
+    }
+    __syncthreads();
+    fft_dif<L, WT, WT>(s, stw, tid);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      out[obase + (long)(q * L + n) * g.out_axis_stride + col] = s[e];
+    }
+  }
+}
+
+// Inverse pass along one axis: 2L (parity, position) in, first L samples out.
+// REAL_OUT: band operator on the way out, re -> sample 2p, im -> sample 2p+1.
+template <int L, int WT, bool REAL_OUT>
+__global__ __launch_bounds__(NT) void k_axis_inv(const float2* __restrict__ in, float2* __restrict__ out,
+                                                 float* __restrict__ yr, int batch, long vol, PassGeom g,
+                                                 const float2* __restrict__ tw, const float2* __restrict__ hs,
+                                                 const int32_t* __restrict__ boff, const int32_t* __restrict__ bidx,
+                                                 const float* __restrict__ bval) {
+  constexpr int EPT = (L * WT) / NT;
+  __shared__ float2 s[L * WT];
+  __shared__ float2 stw[L];
+  __shared__ float2 shs[L];
+  const int tid = threadIdx.x;
+  const int pair = blockIdx.z;
+  const int outer = blockIdx.x / g.chunks_per_outer, chunk = blockIdx.x % g.chunks_per_outer;
+  const long ibase = (long)pair * g.in_pair_stride + (long)outer * g.in_outer_stride + (long)chunk * WT;
+  const long obase = (long)outer * g.out_outer_stride + (long)chunk * WT;
+  for (int i = tid; i < L; i += NT) {
+    stw[i] = tw[i];
+    shs[i] = hs[i];
+  }
+  float2 acc[EPT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      s[e] = in[ibase + (long)(q * L + n) * g.in_axis_stride + col];
+    }
+    __syncthreads();
+    fft_dit<L, WT, WT>(s, stw, tid);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT;
+      acc[k] = q ? cadd(acc[k], cmulc(s[e], shs[n])) : s[e];
+    }
+  }
+  if constexpr (REAL_OUT) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) s[tid + k * NT] = acc[k];
+    __syncthreads();
+    float* y0 = yr + (long)(2 * pair) * vol;
+    const bool has1 = (2 * pair + 1) < batch;
+    float* y1 = yr + (long)(2 * pair + 1) * vol;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      float2 a = make_float2(0.f, 0.f);
+      for (int t = boff[n]; t < boff[n + 1]; ++t) {
+        const float c = bval[t];
+        const float2 v = s[bidx[t] * WT + col];
+        a.x += c * v.x;
+        a.y += c * v.y;
+      }
+      const long gi = obase + (long)n * g.out_axis_stride + col;
+      y0[gi] = a.x;
+      if (has1) y1[gi] = a.y;
+    }
+  } else {
+    float2* op = out + (long)pair * g.out_pair_stride;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      op[obase + (long)n * g.out_axis_stride + col] = acc[k];
+    }
+  }
+}
+
+// Middle pass on contiguous rows of length L (the W axis), in place:
+//   row <- crop( F^-1( H . F( pad(row) ) ) ),  H read once, coalesced.
+template <int L, int RT>
+__global__ __launch_bounds__(NT) void k_axis_mid(float2* __restrict__ data, const float2* __restrict__ H,
+                                                 long pair_stride, long rows_per_pair, int conj_h,
+                                                 const float2* __restrict__ tw, const float2* __restrict__ hs) {
+  constexpr int EPT = (L * RT) / NT;
+  constexpr int LD = RT + 1;
+  __shared__ float2 s[L * LD];
+  __shared__ float2 stw[L];
+  __shared__ float2 shs[L];
+  const int tid = threadIdx.x;
+  const int pair = blockIdx.z;
+  const long row0 = (long)blockIdx.x * RT;
+  float2* base = data + (long)pair * pair_stride + row0 * L;
+  const float2* hbase = H + row0 * (2 * L);
+  for (int i = tid; i < L; i += NT) {
+    stw[i] = tw[i];
+    shs[i] = hs[i];
+  }
+  float2 u[EPT], acc[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) u[k] = base[tid + k * NT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, r = e / L, n = e % L;
+      s[n * LD + r] = q ? cmul(u[k], shs[n]) : u[k];
+    }
+    __syncthreads();
+    fft_dif<L, RT, LD>(s, stw, tid);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, r = e / L, n = e % L;
+      const float2 h = hbase[(long)r * (2 * L) + q * L + n];
+      const float2 v = s[n * LD + r];
+      s[n * LD + r] = conj_h ? cmulc(v, h) : cmul(v, h);
+    }
+    __syncthreads();
+    fft_dit<L, RT, LD>(s, stw, tid);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, r = e / L, n = e % L;
+      const float2 v = s[n * LD + r];
+      acc[k] = q ? cadd(acc[k], cmulc(v, shs[n])) : v;
+    }
+  }
+  (void)rows_per_pair;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) base[tid + k * NT] = acc[k];
+}
+
+// ------------------------------------------------------------------ host side
+static constexpr int tile_width(int L) { return L <= 256 ? 16 : (L == 512 ? 8 : 4); }
+
+// position (after the DIF stages of fft_dif<L>) -> natural frequency of the L-point DFT
+static std::vector<int> dif_position_to_freq(int L) {
+  std::vector<int> radices;
+  int n = L;
+  while (n >= 4) {
+    radices.push_back(4);
+    n >>= 2;
+  }
+  if (n == 2) radices.push_back(2);
+  std::vector<int> k(L);
+  for (int pos = 0; pos < L; ++pos) {
+    int rem = pos, span = L, mult = 1, freq = 0;
+    for (int R : radices) {
+      span /= R;
+      int digit = rem / span;
+      rem %= span;
+      freq += digit * mult;
+      mult *= R;
+    }
+    k[pos] = freq;
+  }
+  return k;
+}
+
+// array position along a doubled axis (parity q, position) -> natural bin of the 2L-point DFT
+static std::vector<int> doubled_axis_perm(int L) {
+  std::vector<int> k = dif_position_to_freq(L), p(2 * L);
+  for (int q = 0; q < 2; ++q)
+    for (int pos = 0; pos < L; ++pos) p[q * L + pos] = 2 * k[pos] + q;
+  return p;
+}
+
+template <typename T>
+static int upload(T** dst, const std::vector<T>& v) {
+  HP_CHECK_HIP(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) HP_CHECK_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return HP_OK;
+}
+
+static int upload_band(BandDev& b, const SparseRows& m) {
+  int rc;
+  if ((rc = upload(&b.off, m.off))) return rc;
+  if ((rc = upload(&b.idx, m.idx))) return rc;
+  return upload(&b.val, m.val);
+}
+
+static void free_band(BandDev& b) {
+  if (b.off) (void)hipFree(b.off);
+  if (b.idx) (void)hipFree(b.idx);
+  if (b.val) (void)hipFree(b.val);
+  b = BandDev();
+}
+
+static int upload_twiddles(int L, float2** tw, float2** hs) {
+  std::vector<float2> a(L), b(L);
+  const double PI = 3.14159265358979323846;
+  for (int p = 0; p < L; ++p) {
+    a[p] = make_float2((float)cos(-2.0 * PI * p / L), (float)sin(-2.0 * PI * p / L));
+    b[p] = make_float2((float)cos(-PI * p / L), (float)sin(-PI * p / L));
+  }
+  int rc;
+  if ((rc = upload(tw, a))) return rc;
+  return upload(hs, b);
+}
+
+static bool supported_len(int L) { return is_pow2(L) && L >= 16 && L <= 1024; }
+
+template <int L, bool REAL_IN>
+static void launch_fwd(dim3 grid, hipStream_t st, const float* xr, const float2* in, float2* out, int batch, long vol,
+                       PassGeom g, const float2* tw, const float2* hs, const BandDev& b) {
+  constexpr int WT = tile_width(L);
+  hipLaunchKernelGGL((k_axis_fwd<L, WT, REAL_IN>), grid, dim3(NT), 0, st, xr, in, out, batch, vol, g, tw, hs, b.off,
+                     b.idx, b.val);
+}
+template <int L, bool REAL_OUT>
+static void launch_inv(dim3 grid, hipStream_t st, const float2* in, float2* out, float* yr, int batch, long vol,
+                       PassGeom g, const float2* tw, const float2* hs, const BandDev& b) {
+  constexpr int WT = tile_width(L);
+  hipLaunchKernelGGL((k_axis_inv<L, WT, REAL_OUT>), grid, dim3(NT), 0, st, in, out, yr, batch, vol, g, tw, hs, b.off,
+                     b.idx, b.val);
+}
+template <int L>
+static void launch_mid(dim3 grid, hipStream_t st, float2* data, const float2* H, long pair_stride, long rows,
+                       int conj_h, const float2* tw, const float2* hs) {
+  constexpr int RT = tile_width(L);
+  hipLaunchKernelGGL((k_axis_mid<L, RT>), grid, dim3(NT), 0, st, data, H, pair_stride, rows, conj_h, tw, hs);
+}
+
+#define HP_DISPATCH_LEN(L, CALL)                 \
+  switch (L) {                                   \
+    case 16: { constexpr int LL = 16; CALL; } break;     \
+    case 32: { constexpr int LL = 32; CALL; } break;     \
+    case 64: { constexpr int LL = 64; CALL; } break;     \
+    case 128: { constexpr int LL = 128; CALL; } break;   \
+    case 256: { constexpr int LL = 256; CALL; } break;   \
+    case 512: { constexpr int LL = 512; CALL; } break;   \
+    case 1024: { constexpr int LL = 1024; CALL; } break; \
+    default: break;                              \
+  }
+
+static int run_lct(const hp_lct_plan* p, const float* x, float* y, int batch, void* ws, size_t ws_bytes,
+                   hipStream_t st, bool backward) {
+  HP_REQUIRE(p && x && y && ws, "hp_lct: null argument");
+  HP_REQUIRE(batch >= 1, "hp_lct: batch must be >= 1 (got %d)", batch);
+  const size_t need = hp_lct_workspace_bytes(p, batch);
+  if (ws_bytes < need) {
+    set_error("hp_lct: workspace too small (%zu < %zu)", ws_bytes, need);
+    return HP_ERR_WORKSPACE;
+  }
+  const int T = p->T, N = p->N, P = (batch + 1) / 2;
+  const long vol = (long)T * N * N;
+  float2* C1 = (float2*)ws;          // [P][2T][N][N]
+  float2* C2 = C1 + (long)P * 2 * vol;  // [P][2T][2N][N]
+  const BandDev& bin = backward ? p->bwd_in : p->fwd_in;
+  const BandDev& bout = backward ? p->bwd_out : p->fwd_out;
+  const int wtT = tile_width(T), wtN = tile_width(N);
+
+  PassGeom g;
+  // 1. T forward (+ band in)
+  g = PassGeom{0, 2 * vol, (int)((long)N * N / wtT), 0, 0, (long)N * N, (long)N * N};
+  HP_DISPATCH_LEN(T, (launch_fwd<LL, true>(dim3(g.chunks_per_outer, 1, P), st, x, nullptr, C1, batch, vol, g, p->twT,
+                                           p->hsT, bin)));
+  // 2. H forward
+  g = PassGeom{2 * vol, 4 * vol, N / wtN, (long)N * N, 2L * N * N, N, N};
+  HP_DISPATCH_LEN(N, (launch_fwd<LL, false>(dim3(2 * T * g.chunks_per_outer, 1, P), st, nullptr, C1, C2, batch, vol, g,
+                                            p->twN, p->hsN, bin)));
+  // 3. W forward . filter . W inverse (in place)
+  {
+    const long rows = 2L * T * 2 * N;
+    HP_DISPATCH_LEN(N, (launch_mid<LL>(dim3((unsigned)(rows / wtN), 1, P), st, C2, p->Hdev, 4 * vol, rows,
+                                       backward ? 1 : 0, p->twN, p->hsN)));
+  }
+  // 4. H inverse
+  g = PassGeom{4 * vol, 2 * vol, N / wtN, 2L * N * N, (long)N * N, N, N};
+  HP_DISPATCH_LEN(N, (launch_inv<LL, false>(dim3(2 * T * g.chunks_per_outer, 1, P), st, C2, C1, nullptr, batch, vol, g,
+                                            p->twN, p->hsN, bout)));
+  // 5. T inverse (+ band out)
+  g = PassGeom{2 * vol, 0, (int)((long)N * N / wtT), 0, 0, (long)N * N, (long)N * N};
+  HP_DISPATCH_LEN(T, (launch_inv<LL, true>(dim3(g.chunks_per_outer, 1, P), st, C1, nullptr, y, batch, vol, g, p->twT,
+                                           p->hsT, bout)));
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" int hp_lct_host_constants(int T, int N, double bin_len, double wall_size, float* gridz, float* mtx,
+                                     int32_t* psf_zidx, int64_t* psf_count, float* invpsf_re, float* invpsf_im) {
+  HP_REQUIRE(is_pow2(T) && T >= 2 && N >= 1, "hp_lct_host_constants: T must be a power of two, N >= 1");
+  LctHost h;
+  lct_host_build(T, N, bin_len, wall_size, h);
+  if (gridz) std::memcpy(gridz, h.gridz.data(), sizeof(float) * T);
+  if (mtx) {
+    std::memset(mtx, 0, sizeof(float) * (size_t)T * T);
+    for (int r = 0; r < T; ++r)
+      for (int e = h.mtx.off[r]; e < h.mtx.off[r + 1]; ++e) mtx[(size_t)r * T + h.mtx.idx[e]] = h.mtx.val[e];
+  }
+  const int N2 = 2 * N, M2 = 2 * T;
+  if (psf_zidx)
+    for (int p = 0; p < N2 * N2; ++p) psf_zidx[p] = h.mark_off[p + 1] > h.mark_off[p] ? h.mark_z[h.mark_off[p]] : -1;
+  if (psf_count) *psf_count = h.count;
+  if (invpsf_re && invpsf_im) {
+    const size_t sl = (size_t)N2 * N2;
+    unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<std::complex<double>> buf(sl);
+        for (int kz = (int)t; kz < M2; kz += (int)nth) {
+          lct_invpsf_slice(h, kz, buf.data(), nullptr);
+          for (size_t i = 0; i < sl; ++i) {
+            invpsf_re[(size_t)kz * sl + i] = (float)buf[i].real();
+            invpsf_im[(size_t)kz * sl + i] = (float)buf[i].imag();
+          }
+        }
+      });
+    for (auto& t : th) t.join();
+  }
+  return HP_OK;
+}
+
+extern "C" int hp_lct_plan_create(hp_lct_plan** out, int T, int N, double bin_len, double wall_size, int material,
+                                  int device) {
+  HP_REQUIRE(out, "hp_lct_plan_create: null out");
+  *out = nullptr;
+  if (!supported_len(T) || !supported_len(N)) {
+    set_error("hp_lct_plan_create: T and N must be powers of two in [16,1024] (got T=%d N=%d)", T, N);
+    return HP_ERR_UNSUPPORTED;
+  }
+  HP_REQUIRE(material == HP_MATERIAL_DIFFUSE || material == HP_MATERIAL_SPECULAR, "bad material %d", material);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("hp_lct_plan_create: no HIP device available");
+    return HP_ERR_NO_DEVICE;
+  }
+  HP_REQUIRE(device >= 0 && device < ndev, "hp_lct_plan_create: device %d out of range (%d devices)", device, ndev);
+  HP_CHECK_HIP(hipSetDevice(device));
+
+  hp_lct_plan* p = new hp_lct_plan();
+  p->T = T;
+  p->N = N;
+  p->material = material;
+  p->device = device;
+  lct_host_build(T, N, bin_len, wall_size, p->host);
+  p->permT = doubled_axis_perm(T);
+  p->permN = doubled_axis_perm(N);
+
+  // band operators. forward: in = mtx.diag(g^k), out = mtx^T ; backward: in = mtx, out = diag(g^k).mtx^T
+  const int gp = material == HP_MATERIAL_DIFFUSE ? 4 : 2;
+  std::vector<float> gk(T);
+  for (int t = 0; t < T; ++t) {
+    float g = p->host.gridz[t], v = g * g;
+    gk[t] = gp == 4 ? v * v : v;
+  }
+  SparseRows fin = p->host.mtx;
+  for (size_t e = 0; e < fin.idx.size(); ++e) fin.val[e] *= gk[fin.idx[e]];
+  SparseRows mT = p->host.mtx.transposed(T);
+  SparseRows bout = mT;
+  for (int r = 0; r < T; ++r)
+    for (int e = bout.off[r]; e < bout.off[r + 1]; ++e) bout.val[e] *= gk[r];
+  int rc = HP_OK;
+  auto fail = [&](int code) {
+    hp_lct_plan_destroy(p);
+    return code;
+  };
+  if ((rc = upload_band(p->fwd_in, fin))) return fail(rc);
+  if ((rc = upload_band(p->fwd_out, mT))) return fail(rc);
+  if ((rc = upload_band(p->bwd_in, p->host.mtx))) return fail(rc);
+  if ((rc = upload_band(p->bwd_out, bout))) return fail(rc);
+  if ((rc = upload_twiddles(T, &p->twT, &p->hsT))) return fail(rc);
+  if ((rc = upload_twiddles(N, &p->twN, &p->hsN))) return fail(rc);
+
+  // inverse PSF spectrum, permuted to the DIF/DIT bin order of the device passes and
+  // pre-scaled by 1/(2T.2N.2N); built slice by slice (threads over kz) in pinned-size chunks.
+  const int N2 = 2 * N, M2 = 2 * T;
+  const size_t sl = (size_t)N2 * N2;
+  const double scale = 1.0 / ((double)M2 * N2 * N2);
+  if (hipMalloc((void**)&p->Hdev, sizeof(float2) * sl * M2) != hipSuccess) {
+    set_error("hp_lct_plan_create: hipMalloc of %zu bytes for invpsf failed", sizeof(float2) * sl * M2);
+    return fail(HP_ERR_HIP);
+  }
+  {
+    std::vector<float2> hostH(sl * M2);
+    unsigned nth = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    const std::vector<int>& pT = p->permT;
+    const std::vector<int>& pN = p->permN;
+    const LctHost& hh = p->host;
+    for (unsigned t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<std::complex<double>> buf(sl);
+        for (int at = (int)t; at < M2; at += (int)nth) {
+          lct_invpsf_slice(hh, pT[at], buf.data(), nullptr);
+          float2* dst = hostH.data() + (size_t)at * sl;
+          for (int ah = 0; ah < N2; ++ah) {
+            const std::complex<double>* src = buf.data() + (size_t)pN[ah] * N2;
+            for (int aw = 0; aw < N2; ++aw) {
+              std::complex<double> v = src[pN[aw]] * scale;
+              dst[(size_t)ah * N2 + aw] = make_float2((float)v.real(), (float)v.imag());
+            }
+          }
+        }
+      });
+    for (auto& t : th) t.join();
+    if (hipMemcpy(p->Hdev, hostH.data(), sizeof(float2) * sl * M2, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("hp_lct_plan_create: upload of invpsf failed");
+      return fail(HP_ERR_HIP);
+    }
+  }
+  *out = p;
+  return HP_OK;
+}
+
+extern "C" int hp_lct_plan_destroy(hp_lct_plan* p) {
+  if (!p) return HP_OK;
+  (void)hipSetDevice(p->device);
+  if (p->Hdev) (void)hipFree(p->Hdev);
+  for (float2* q : {p->twT, p->hsT, p->twN, p->hsN})
+    if (q) (void)hipFree(q);
+  free_band(p->fwd_in);
+  free_band(p->fwd_out);
+  free_band(p->bwd_in);
+  free_band(p->bwd_out);
+  delete p;
+  return HP_OK;
+}
+
+extern "C" size_t hp_lct_workspace_bytes(const hp_lct_plan* p, int batch) {
+  if (!p || batch < 1) return 0;
+  const size_t P = (size_t)(batch + 1) / 2;
+  return P * 6 * (size_t)p->T * p->N * p->N * sizeof(float2);
+}
+
+extern "C" int hp_lct_forward(const hp_lct_plan* p, const float* x, float* y, int batch, void* ws, size_t ws_bytes,
+                              void* stream) {
+  return run_lct(p, x, y, batch, ws, ws_bytes, (hipStream_t)stream, false);
+}
+
+extern "C" int hp_lct_backward(const hp_lct_plan* p, const float* gy, float* gx, int batch, void* ws, size_t ws_bytes,
+                               void* stream) {
+  return run_lct(p, gy, gx, batch, ws, ws_bytes, (hipStream_t)stream, true);
+}
+
+extern "C" int hp_lct_plan_get_invpsf(const hp_lct_plan* p, float* re, float* im) {
+  HP_REQUIRE(p && re && im, "hp_lct_plan_get_invpsf: null argument");
+  const int N2 = 2 * p->N, M2 = 2 * p->T;
+  const size_t sl = (size_t)N2 * N2;
+  std::vector<float2> h(sl * M2);
+  HP_CHECK_HIP(hipSetDevice(p->device));
+  HP_CHECK_HIP(hipMemcpy(h.data(), p->Hdev, sizeof(float2) * sl * M2, hipMemcpyDeviceToHost));
+  const double unscale = (double)M2 * N2 * N2;
+  for (int at = 0; at < M2; ++at)
+    for (int ah = 0; ah < N2; ++ah)
+      for (int aw = 0; aw < N2; ++aw) {
+        const float2 v = h[(size_t)at * sl + (size_t)ah * N2 + aw];
+        const size_t o = (size_t)p->permT[at] * sl + (size_t)p->permN[ah] * N2 + p->permN[aw];
+        re[o] = (float)(v.x * unscale);
+        im[o] = (float)(v.y * unscale);
+      }
+  return HP_OK;
+}

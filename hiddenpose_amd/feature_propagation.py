@@ -1,0 +1,139 @@
+"""Physics layer of NlosPose: the light-cone transform (LCT).
+
+Drop-in for the reference's models/feature_propagation.py:
+`FeaturePropagation(image_size, time_size, bin_len, wall_size, mode, material, dnum, dev)`
+with `.forward(x, time_begin, time_end)` (:18-44), `LCT` (:46-257) and
+`normalize_feature` (:273-286).  All arithmetic runs in libhiddenpose_hip.so
+(hp_lct_* / hp_normalize_*); there is no torch or CPU fallback.
+
+Differences from the reference, on purpose:
+  * any batch size (the reference indexes 3-element time_begin/time_end lists, B <= 3);
+  * constants live on the device of the input tensor (the reference hard-codes 'cuda');
+  * only tbe = 0, ten = T is accepted -- the only case NlosPose issues
+    (models/NlosPose.py:53); other windows raise.
+"""
+from __future__ import annotations
+
+import threading
+import weakref
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+_MATERIAL = {"diffuse": 0, "specular": 1}
+
+
+class LCTPlan:
+    """Owner of one hp_lct_plan (device constants: inverse PSF spectrum, band tables,
+    twiddles).  Replaces LCT._parpareparam + todev (feature_propagation.py:71-184)."""
+
+    def __init__(self, T: int, N: int, bin_len: float, wall_size: float, material: str, device: torch.device):
+        import ctypes as C
+
+        self.T, self.N, self.device = T, N, torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HiddenPoseHipError("LCTPlan needs a HIP device (tensor on %s)" % self.device)
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(_lib.lib().hp_lct_plan_create(C.byref(h), T, N, float(bin_len), float(wall_size),
+                                                 _MATERIAL[material], idx), "hp_lct_plan_create")
+        self.handle = h
+        self._finalizer = weakref.finalize(self, _lib.lib().hp_lct_plan_destroy, h)
+
+    def workspace_bytes(self, batch: int) -> int:
+        return int(_lib.lib().hp_lct_workspace_bytes(self.handle, batch))
+
+    def run(self, x: torch.Tensor, backward: bool) -> torch.Tensor:
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        batch = x.numel() // (self.T * self.N * self.N)
+        y = torch.empty_like(x)
+        nbytes = self.workspace_bytes(batch)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        fn = _lib.lib().hp_lct_backward if backward else _lib.lib().hp_lct_forward
+        with torch.cuda.device(x.device):
+            _lib.check(fn(self.handle, x.data_ptr(), y.data_ptr(), batch, ws.data_ptr(), nbytes,
+                          _lib.current_stream_handle(x.device)), "hp_lct_backward" if backward else "hp_lct_forward")
+        return y
+
+    def invpsf(self):
+        n = 8 * self.T * self.N * self.N
+        re = np.empty(n, np.float32)
+        im = np.empty(n, np.float32)
+        _lib.check(_lib.lib().hp_lct_plan_get_invpsf(self.handle, re.ctypes.data, im.ctypes.data), "get_invpsf")
+        shp = (2 * self.T, 2 * self.N, 2 * self.N)
+        return re.reshape(shp), im.reshape(shp)
+
+
+class _LCTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        return plan.run(x.contiguous(), backward=False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ctx.plan.run(gy.contiguous(), backward=True), None
+
+
+class LCT(nn.Module):
+    """models/feature_propagation.py:46-257 (mode 'lct')."""
+
+    def __init__(self, image_size=256, time_size=128, bin_len=0.01, wall_size=2.0, mode="lct", material="diffuse"):
+        super().__init__()
+        assert mode == "lct", f"{mode} is not spported. Feature propagation only support lct by now"
+        assert 2 ** int(np.log2(time_size)) == time_size, "time size should be a power of 2"
+        assert material in _MATERIAL
+        _lib.lib()  # the HIP extension is mandatory
+        self.image_size, self.time_size = int(image_size), int(time_size)
+        self.bin_len, self.wall_size, self.mode, self.material = bin_len, wall_size, mode, material
+        self._plans = {}
+        self._plock = threading.Lock()
+
+    def todev(self, dev, dnum=1):
+        """Reference API (:173-184).  Constants are created per device on first use;
+        calling this merely pre-builds the plan for `dev`."""
+        d = torch.device("cuda", dev) if isinstance(dev, int) else torch.device(dev)
+        if d.type == "cuda":
+            self.plan_for(d)
+        return self
+
+    def plan_for(self, device: torch.device) -> LCTPlan:
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        with self._plock:
+            p = self._plans.get(device)
+            if p is None:
+                p = LCTPlan(self.time_size, self.image_size, self.bin_len, self.wall_size, self.material, device)
+                self._plans[device] = p
+        return p
+
+    def forward(self, feture_bxdxtxhxw, tbes=None, tens=None):
+        x = feture_bxdxtxhxw
+        b, d, t, h, w = x.shape
+        if tbes is not None:
+            for tbe, ten in zip(tbes, tens):
+                assert tbe >= 0 and ten <= self.time_size
+                if tbe != 0 or ten != self.time_size:
+                    raise NotImplementedError("only the full window tbe=0, ten=time_size is supported")
+        assert t == self.time_size and h == w == self.image_size
+        if not x.is_cuda:
+            raise _lib.HiddenPoseHipError("LCT.forward needs a tensor on a HIP device; there is no CPU path")
+        y = _LCTFunction.apply(x.reshape(b * d, t, h, w).float(), self.plan_for(x.device))
+        return y.view(b, d, t, h, w)
+
+
+class FeaturePropagation(nn.Module):
+    """models/feature_propagation.py:18-44.  (B,C,T,H,W) -> (B,C,T,H,W)."""
+
+    def __init__(self, image_size=256, time_size=512, bin_len=0.01, wall_size=2.0, mode="lct", material="diffuse",
+                 dnum=1, dev="cpu"):
+        super().__init__()
+        assert mode == "lct", f"{mode} is not spported. Feature propagation only support lct by now"
+        self.method = LCT(int(image_size), time_size, bin_len, wall_size, mode=mode, material=material)
+
+    def forward(self, x, time_begin=None, time_end=None):
+        return self.method(x, time_begin, time_end)

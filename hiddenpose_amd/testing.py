@@ -1,0 +1,118 @@
+"""Deterministic synthetic inputs and weight filler shared by tests, bench.py,
+smoke() and the golden generator (tests/golden/make_goldens.py).
+
+Nothing here is part of the hot path.  Neither the reference's trained weights
+nor its datasets exist offline (reference README.md:36,111), so parity is
+measured on synthetic transients with weights filled by a closed, seeded rule
+that both the reference modules and this package's modules receive by
+parameter *name* (the state_dict schemas are identical).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng_for(name: str, salt: int = 0) -> np.random.Generator:
+    seed = zlib.crc32(name.encode("utf-8")) ^ (salt * 0x9E3779B1 & 0xFFFFFFFF)
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def fill_value(name: str, shape, head_gain: float = 6.0) -> torch.Tensor:
+    """Value for the parameter/buffer called `name` with `shape`.
+
+    conv / deconv weights : N(0, 2/fan_in)        (activations stay O(1))
+    norm weights          : 1 + 0.1 N(0,1);  norm/conv biases: 0.1 N(0,1)
+    running_mean          : 0.1 N(0,1);      running_var: 1 + 0.1 |N(0,1)|
+    FeatureExtraction.weights keeps the reference's 8-tap box filter
+    (models/feature_extraction.py:141-145) plus a small perturbation.
+    The last 1x1x1 conv of the pose head is scaled by `head_gain` so the
+    64^3 soft-max is peaked; with the reference's own init every joint
+    decodes to the volume centre and any output would pass.
+    """
+    shape = tuple(int(s) for s in shape)
+    g = _rng_for(name)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return torch.zeros(shape, dtype=torch.long)
+    if leaf == "running_mean":
+        return torch.from_numpy((0.1 * g.standard_normal(shape)).astype(np.float32))
+    if leaf == "running_var":
+        return torch.from_numpy((1.0 + 0.1 * np.abs(g.standard_normal(shape))).astype(np.float32))
+    if name == "feature_extraction.weights":
+        w = np.zeros(shape, dtype=np.float32)
+        w[:, :, 1:, 1:, 1:] = 1.0 / 8.0
+        w += (0.02 * g.standard_normal(shape)).astype(np.float32)
+        return torch.from_numpy(w)
+    if len(shape) == 1:
+        if leaf == "weight":
+            # damp the residual branches so eval-mode activations (running stats ~ N(0,1),
+            # i.e. no real normalisation) stay O(1) through the 16 bottlenecks
+            gain = 0.25 if name.endswith("bn3.weight") else 0.7 if name.endswith("downsample.1.weight") else 1.0
+            return torch.from_numpy((gain * (1.0 + 0.1 * g.standard_normal(shape))).astype(np.float32))
+        return torch.from_numpy((0.1 * g.standard_normal(shape)).astype(np.float32))
+    # conv (Cout,Cin,k,k,k) or transposed conv (Cin,Cout,k,k,k)
+    fan_in = int(np.prod(shape[1:]))
+    if ".head.features." in name and len(shape) == 5 and shape[2] == 4:
+        # ConvTranspose3d k4 s2 p1: each output voxel sees 2^3 taps per input channel
+        fan_in = shape[0] * 8
+    std = np.sqrt(2.0 / fan_in)
+    if name.endswith("head.features.9.weight"):
+        std *= head_gain
+    if name.endswith("pose_net.conv1.weight"):
+        std *= 0.1  # stem sees inputs in [0, 10+]
+    return torch.from_numpy((std * g.standard_normal(shape)).astype(np.float32))
+
+
+@torch.no_grad()
+def fill_module(module: torch.nn.Module, prefix: str = "", head_gain: float = 6.0) -> None:
+    """Overwrite every tensor of module.state_dict() with fill_value(prefix+key)."""
+    sd = module.state_dict()
+    for key, t in sd.items():
+        v = fill_value(prefix + key, t.shape, head_gain)
+        t.copy_(v.to(dtype=t.dtype, device=t.device))
+
+
+def synthetic_meas(batch: int, T: int, N: int, kind: str = "transient", seed: int = 410) -> torch.Tensor:
+    """(B,1,T,N,N) float32 in [0,1].  kind='transient': Poisson counts around a
+    paraboloid arrival surface; kind='uniform': U[0,1)."""
+    out = torch.empty(batch, 1, T, N, N, dtype=torch.float32)
+    for b in range(batch):
+        g = torch.Generator().manual_seed(seed + b)
+        if kind == "uniform":
+            out[b, 0] = torch.rand(T, N, N, generator=g)
+            continue
+        hh = torch.linspace(-1.0, 1.0, N).view(1, N, 1)
+        ww = torch.linspace(-1.0, 1.0, N).view(1, 1, N)
+        cx = 0.3 * torch.rand(1, generator=g).item() - 0.15
+        cy = 0.3 * torch.rand(1, generator=g).item() - 0.15
+        t0 = T * (0.30 + 0.25 * ((hh - cy) ** 2 + (ww - cx) ** 2))
+        tt = torch.arange(T, dtype=torch.float32).view(T, 1, 1)
+        sigma = max(3.0 * T / 128.0, 1.5)
+        lam = 20.0 * torch.exp(-((tt - t0) ** 2) / (2.0 * sigma * sigma)) + 0.05
+        cnt = torch.poisson(lam, generator=g)
+        out[b, 0] = cnt / cnt.max().clamp_min(1.0)
+    return out
+
+
+def synthetic_vol(batch: int, T: int, N: int, seed: int = 1) -> torch.Tensor:
+    """Binary occupancy target (B,1,T,N,N), about 2 % ones."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(batch, 1, T, N, N, generator=g) < 0.02).to(torch.float32)
+
+
+def synthetic_joints(batch: int, hm: int, seed: int = 2, num_joints: int = 24) -> torch.Tensor:
+    """(B, J, 3) joint targets in heat-map voxel units inside the central 3/4."""
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = hm / 8.0, hm * 7.0 / 8.0
+    return lo + (hi - lo) * torch.rand(batch, num_joints, 3, generator=g)
+
+
+def mpjpe(pred: torch.Tensor, ref: torch.Tensor, num_joints: int = 24) -> float:
+    """Mean per-joint position error in heat-map voxels between two (B,3J) decodes
+    (definition: SURVEY.md 8d; x31.25 gives mm for the 2 m wall / 64 voxels)."""
+    p = pred.reshape(pred.shape[0], num_joints, 3).double()
+    r = ref.reshape(ref.shape[0], num_joints, 3).double()
+    return (p - r).norm(dim=2).mean().item()

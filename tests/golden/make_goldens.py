@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by importing the reference
+(read-only checkout at /root/reference) through ref_shims.install().
+
+Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
+Sections: consts lct parts posenet e2e e2e128 softargmax   (default: all)
+
+Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
+its filler keyed by state_dict name, so tests rebuild identical inputs and
+weights without committing them.  Only reference OUTPUTS are stored.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+from hiddenpose_amd import testing as hpt  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+BIN_LEN = {(32, 16): 0.16, (32, 32): 0.16, (128, 128): 0.04, (512, 128): 0.01, (64, 32): 0.08}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def sample_idx(n_total: int, n: int, seed: int) -> np.ndarray:
+    return np.random.Generator(np.random.PCG64(seed)).choice(n_total, size=n, replace=False).astype(np.int64)
+
+
+def sec_consts():
+    import models.feature_propagation as fp
+
+    out = {}
+    for (T, N) in [(32, 16), (128, 128), (512, 128)]:
+        t0 = time.time()
+        lct = fp.LCT(N, T, BIN_LEN[(T, N)], 2.0)
+        tag = f"T{T}_N{N}"
+        mtx = lct.mtx_MxM.numpy()
+        r, c = np.nonzero(mtx)
+        out[f"{tag}_mtx_rows"] = r.astype(np.int32)
+        out[f"{tag}_mtx_cols"] = c.astype(np.int32)
+        out[f"{tag}_mtx_vals"] = mtx[r, c]
+        out[f"{tag}_gridz"] = lct.gridz_1xMx1x1.numpy().reshape(-1)
+        slope = lct.width / lct.trange
+        out[f"{tag}_slope"] = np.float64(slope)
+        psf = lct._definePsf(N, T, slope)
+        ind = (psf > 0).astype(np.uint8)
+        out[f"{tag}_psf_sha1"] = np.frombuffer(hashlib.sha1(ind.tobytes()).digest(), dtype=np.uint8)
+        out[f"{tag}_psf_nnz"] = np.int64(ind.sum())
+        out[f"{tag}_psf_val"] = np.float32(psf.max())
+        # z index of the single 1 in every (x,y) column, after the roll (layout (2M,2N,2N))
+        out[f"{tag}_psf_zidx"] = ind.argmax(axis=0).astype(np.int16)
+        re = lct.invpsf_real.numpy()[0]
+        im = lct.invpsf_imag.numpy()[0]
+        if T * N * N <= 32 * 16 * 16:
+            out[f"{tag}_invpsf_re"] = re
+            out[f"{tag}_invpsf_im"] = im
+        else:
+            idx = sample_idx(re.size, 512, 7)
+            out[f"{tag}_invpsf_idx"] = idx
+            out[f"{tag}_invpsf_re_s"] = re.reshape(-1)[idx]
+            out[f"{tag}_invpsf_im_s"] = im.reshape(-1)[idx]
+        out[f"{tag}_invpsf_l2"] = np.float64(np.sqrt((re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2).sum()))
+        print(f"  consts {tag}: {time.time()-t0:.1f}s nnz(mtx)={len(r)}")
+    save("lct_consts.npz", **out)
+
+
+def sec_lct():
+    import models.feature_propagation as fp
+
+    out = {}
+    # small: full tensors
+    T, N, B = 32, 16, 2
+    lct = fp.LCT(N, T, BIN_LEN[(T, N)], 2.0)
+    x = hpt.synthetic_meas(B, T, N, "uniform", seed=0).requires_grad_(True)
+    y = lct(x, [0] * B, [T] * B)
+    gy = hpt.synthetic_meas(B, T, N, "uniform", seed=100) - 0.5
+    (y * gy).sum().backward()
+    out["small_y"] = y.detach().numpy()
+    out["small_gx"] = x.grad.numpy()
+    # B=3 with the transient generator (odd batch)
+    x3 = hpt.synthetic_meas(3, T, N, "transient", seed=410)
+    out["small3_y"] = lct(x3, [0] * 3, [T] * 3).detach().numpy()
+    # large: sampled
+    for (T, N) in [(128, 128), (512, 128)]:
+        lct = fp.LCT(N, T, BIN_LEN[(T, N)], 2.0)
+        x = hpt.synthetic_meas(1, T, N, "transient", seed=410).requires_grad_(True)
+        t0 = time.time()
+        y = lct(x, [0], [T])
+        gy = hpt.synthetic_meas(1, T, N, "uniform", seed=100) - 0.5
+        (y * gy).sum().backward()
+        tag = f"T{T}_N{N}"
+        idx = sample_idx(y.numel(), 1024, 11)
+        yn = y.detach().numpy().reshape(-1)
+        gn = x.grad.numpy().reshape(-1)
+        out[f"{tag}_idx"] = idx
+        out[f"{tag}_y_s"] = yn[idx]
+        out[f"{tag}_gx_s"] = gn[idx]
+        out[f"{tag}_y_l2"] = np.float64(np.sqrt((yn.astype(np.float64) ** 2).sum()))
+        out[f"{tag}_gx_l2"] = np.float64(np.sqrt((gn.astype(np.float64) ** 2).sum()))
+        out[f"{tag}_y_minmax"] = np.array([yn.min(), yn.max()], dtype=np.float32)
+        print(f"  lct {tag}: fwd+bwd {time.time()-t0:.1f}s")
+    save("lct_io.npz", **out)
+
+
+def sec_parts():
+    """FeatureExtraction, normalize_feature, UNet3d on (B=2, T=32, N=32)."""
+    from models.feature_extraction import FeatureExtraction
+    from models.feature_propagation import normalize_feature
+    from unet.unet3d import UNet3d
+
+    B, T, N = 2, 32, 32
+    out = {}
+    x = hpt.synthetic_meas(B, T, N, "transient", seed=410)
+
+    fe = FeatureExtraction(basedim=1, in_channels=1, stride=1)
+    hpt.fill_module(fe, "feature_extraction.")
+    xi = x.clone().requires_grad_(True)
+    y = fe(xi)
+    gy = hpt.synthetic_meas(B, T, N, "uniform", seed=101) - 0.5
+    (y * gy).sum().backward()
+    out["fe_y"] = y.detach().numpy()
+    out["fe_gx"] = xi.grad.numpy()
+    for k, p in fe.named_parameters():
+        out["fe_g_" + k] = p.grad.numpy()
+
+    z = (hpt.synthetic_meas(B, T, N, "uniform", seed=102) - 0.3) * 1e-4
+    zi = z.clone().requires_grad_(True)
+    nz = normalize_feature(zi)
+    (nz * gy).sum().backward()
+    out["norm_y"] = nz.detach().numpy()
+    out["norm_gx"] = zi.grad.numpy()
+
+    un = UNet3d(in_channels=1, n_channels=4)
+    hpt.fill_module(un, "autoencoder.")
+    ui = (hpt.synthetic_meas(B, T, N, "uniform", seed=103) * 10.0).requires_grad_(True)
+    uy = un(ui)
+    (uy * gy).sum().backward()
+    out["unet_y"] = uy.detach().numpy()
+    out["unet_gx"] = ui.grad.numpy()
+    for k in ["conv.double_conv.0.weight", "conv.double_conv.1.weight", "enc4.encoder.1.double_conv.3.weight",
+              "dec1.conv.double_conv.0.weight", "dec4.conv.double_conv.4.bias", "out.conv.weight", "out.conv.bias"]:
+        out["unet_g_" + k] = dict(un.named_parameters())[k].grad.numpy()
+    save("parts_io.npz", **out)
+
+
+def sec_posenet():
+    from models.posenet3d_50 import get_pose_net_50
+
+    out = {}
+    net = get_pose_net_50()
+    hpt.fill_module(net, "pose_net.")
+    x = hpt.synthetic_meas(1, 32, 32, "uniform", seed=104) * 10.0
+    net.eval()
+    with torch.no_grad():
+        out["eval_y"] = net(x).numpy()
+    net.train()
+    x2 = hpt.synthetic_meas(2, 32, 32, "uniform", seed=105) * 10.0
+    xi = x2.clone().requires_grad_(True)
+    y = net(xi)
+    gy = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * gy).sum().backward()
+    out["train_y"] = y.detach().numpy()
+    out["train_gx"] = xi.grad.numpy()
+    sd = net.state_dict()
+    out["train_bn1_running_mean"] = sd["bn1.running_mean"].numpy()
+    out["train_bn1_running_var"] = sd["bn1.running_var"].numpy()
+    out["train_head7_running_var"] = sd["head.features.7.running_var"].numpy()
+    named = dict(net.named_parameters())
+    for k in ["conv1.weight", "bn1.weight", "layer1.0.conv2.weight", "layer1.0.downsample.0.weight",
+              "layer2.0.conv2.weight", "layer3.5.conv3.weight", "layer4.2.bn3.bias",
+              "head.features.0.weight", "head.features.6.weight", "head.features.9.weight", "head.features.9.bias"]:
+        g = named[k].grad.numpy()
+        if g.size > 70000:
+            idx = sample_idx(g.size, 4096, 13)
+            out["train_gidx_" + k] = idx
+            out["train_gs_" + k] = g.reshape(-1)[idx]
+            out["train_gl2_" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        else:
+            out["train_g_" + k] = g
+    save("posenet_io.npz", **out)
+
+
+E2E_PARAMS = ["feature_extraction.weights", "feature_extraction.conv1.1.weight", "feature_extraction.conv1.3.tmp.4.bias",
+              "autoencoder.conv.double_conv.0.weight", "autoencoder.out.conv.bias", "pose_net.conv1.weight",
+              "pose_net.layer2.0.conv2.weight", "pose_net.head.features.9.bias", "pose_net.bn1.weight"]
+
+
+def _e2e(T, N, B, full):
+    from models.NlosPose import NlosPose
+    from utils.criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
+
+    cfg = ref_shims.make_cfg(T, N, BIN_LEN[(T, N)])
+    model = NlosPose(cfg)
+    hpt.fill_module(model)
+    out = {}
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410)
+    vol = hpt.synthetic_vol(B, T, N)
+    joints = hpt.synthetic_joints(B, T // 2).reshape(B, -1)
+    hm = (N // 2, N // 2, T // 2)
+
+    model.eval()
+    t0 = time.time()
+    with torch.no_grad():
+        heat_e, refine_e = model(meas)
+        j_e = softmax_integral_tensor(heat_e, 24, True, hm[0], hm[1], hm[2])
+    print(f"  e2e T{T} N{N} B{B}: eval fwd {time.time()-t0:.1f}s  softmax peak {torch.softmax(heat_e.reshape(B,24,-1),2).max().item():.3g}")
+    out["eval_joints"] = j_e.numpy()
+    out["eval_heat_l2_per_joint"] = heat_e.reshape(B, 24, -1).double().norm(dim=2).numpy()
+    if full:
+        out["eval_heat"] = heat_e.numpy()
+        out["eval_refine"] = refine_e.numpy()
+    else:
+        out["eval_heat_sub"] = heat_e[:, :, ::8, ::8, ::8].numpy()
+        out["eval_refine_sub"] = refine_e[:, :, ::8, ::8, ::8].numpy()
+        out["eval_refine_l2"] = np.float64(refine_e.double().norm().item())
+
+    if full:
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        heat, refine = model(meas)
+        jl = L2JointLocationLoss(output_3d=True)(heat, joints, torch.ones_like(joints))
+        vl = BCEDiceLoss()(refine.reshape(B, -1), vol.reshape(B, -1))
+        loss = jl + vl
+        opt.zero_grad()
+        loss.backward()
+        out["train_heat"] = heat.detach().numpy()
+        out["train_refine"] = refine.detach().numpy()
+        out["train_joints"] = softmax_integral_tensor(heat.detach(), 24, True, hm[0], hm[1], hm[2]).numpy()
+        out["train_joint_loss"] = np.float64(jl.item())
+        out["train_voxel_loss"] = np.float64(vl.item())
+        named = dict(model.named_parameters())
+        for k in E2E_PARAMS:
+            out["grad_" + k] = named[k].grad.numpy().copy()
+        opt.step()
+        for k in E2E_PARAMS:
+            out["adam1_" + k] = named[k].detach().numpy().copy()
+        out["adam1_bn1_running_mean"] = model.state_dict()["pose_net.bn1.running_mean"].numpy()
+    return out
+
+
+def sec_e2e():
+    save("e2e_T32_N32.npz", **_e2e(32, 32, 2, True))
+
+
+def sec_e2e128():
+    save("e2e_T128_N128.npz", **_e2e(128, 128, 1, False))
+
+
+def sec_softargmax():
+    """The reference's own known-answer demo (utils/criterion.py:420-437): -1000
+    background, +1 at one voxel per joint => decode returns that voxel, loss ~ 0."""
+    from utils.criterion import L2JointLocationLoss, softmax_integral_tensor
+
+    B, J, D = 1, 24, 5
+    inp = torch.zeros(B, J, D, D, D) - 1000
+    for j in range(J):
+        inp[0, j, 0, 0, 0] = 1 if j != 0 else -1000
+    inp[0, 0, 1, 1, 1] = 1.0
+    gt = torch.zeros(B, J, 3)
+    gt[0, 0] = torch.tensor([1.0, 1.0, 1.0])
+    gt = gt.reshape(B, J * 3)
+    pred = softmax_integral_tensor(inp, J, True, D, D, D)
+    loss = L2JointLocationLoss(output_3d=True)(inp, gt, torch.ones_like(gt))
+    # a non-trivial random case too, anisotropic dims (W,H,D)=(6,5,4)
+    g = torch.Generator().manual_seed(3)
+    r = torch.randn(2, 24, 4, 5, 6, generator=g) * 3
+    rp = softmax_integral_tensor(r, 24, True, 6, 5, 4)
+    save("softargmax.npz", demo_pred=pred.numpy(), demo_loss=np.float64(loss.item()), rand_pred=rp.numpy())
+
+
+SECTIONS = {"consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
+            "e2e": sec_e2e, "e2e128": sec_e2e128, "softargmax": sec_softargmax}
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        print(f"[{s}]")
+        t0 = time.time()
+        SECTIONS[s]()
+        print(f"[{s}] done in {time.time()-t0:.1f}s")
