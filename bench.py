@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NlosPose training step (forward + loss + backward + Adam) on
+synthetic 128x128x512 transients, batch 4 per GPU, fp32 (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; for N > 1 gradients are averaged with bucketed RCCL all-reduce
+overlapped with backward (hiddenpose_amd/data_parallel.py).  Per-GPU batch is fixed,
+so scaling is weak.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- the dominant hand-written HIP kernel of the timed region, timed with HIP
+                  events on its launch stream inside the library (hp_profile_*); achieved =
+                  algorithmic bytes (or flops) per launch / mean launch duration.
+  cpu_baseline -- the oracle (CPU restatement of the reference, oracle/) timed on this
+                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (T, N, per-GPU batch)
+    "t512": (512, 128, 4),     # BASELINE.json metric: "128x128x512 meas", configs[1] batch 4
+    "native": (128, 128, 4),   # the reference's own training shape (train.py:77-86)
+    "tiny": (32, 32, 2),
+}
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def algorithmic_work(kernel: str, T: int, N: int, B: int):
+    """(bound, unit amount per launch) for each hand-written kernel; derivations in DESIGN.md.
+    V = T*N*N voxels, P = ceil(B/2) packed pairs, complex64 = 8 B."""
+    V = T * N * N
+    P = (B + 1) // 2
+    table = {
+        # real volumes in (4 B/voxel/sample) -> packed spectrum halves out (2 x 8 B/voxel/pair)
+        "lct_axis_fwd_t": ("hbm", 4 * V * B + 16 * V * P),
+        "lct_axis_fwd_h": ("hbm", 16 * V * P + 32 * V * P),
+        # rows in + rows out + one read of the inverse PSF spectrum (8V complex)
+        "lct_axis_mid_w": ("hbm", 32 * V * P * 2 + 64 * V),
+        "lct_axis_inv_h": ("hbm", 32 * V * P + 16 * V * P),
+        "lct_axis_inv_t": ("hbm", 16 * V * P + 4 * V * B),
+    }
+    return table.get(kernel)
+
+
+def cpu_baseline(threads: int):
+    """Oracle train step (fwd + losses + bwd + Adam) on ONE 128x128x128 cube = 1/4 of a
+    128x128x512 sample; value is scaled to 128x128x512 samples/s."""
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.NlosPose import NlosPose
+    from oracle import nlospose_oracle as O
+
+    torch.set_num_threads(threads)
+    T, N, B = 128, 128, 1
+    model = NlosPose(make_cfg(T, N))
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in model.state_dict().items()}
+    k = O.LCTConstants(N, T, 0.04)
+    meas = hpt.synthetic_meas(B, T, N)
+    vol = hpt.synthetic_vol(B, T, N)
+    joints = hpt.synthetic_joints(B, T // 2).reshape(B, -1)
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
+    t0 = time.perf_counter()
+    loss, *_ = O.train_loss(meas, vol, joints, sd, k)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": round(0.25 / dt, 6), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 cube of 128x128x128 (1/4 of a 128x128x512 sample), oracle fwd+loss+bwd+Adam, {dt:.1f} s, "
+                      f"scaled x1/4; torch CPU fp32, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hiddenpose_amd import _lib
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.data_parallel import GradBucketReducer
+    from hiddenpose_amd.NlosPose import NlosPose
+    from hiddenpose_amd.train_epoch import build_training, seed_everything, train_step
+
+    T, N, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    cfg = make_cfg(T, N, device=local)
+    seed_everything(410)
+    model = NlosPose(cfg).to(dev)
+    model.train()
+    criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb) if world > 1 else None
+
+    # synthetic batch of this rank (different samples per rank), resident in HBM before timing
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410 + rank * B).to(dev)
+    vol = hpt.synthetic_vol(B, T, N, seed=1 + rank).to(dev)
+    joints = hpt.synthetic_joints(B, T // 2, seed=2 + rank).to(dev)
+
+    def step():
+        return train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"workload {args.workload}: T={T} N={N} batch/GPU={B} world={world}")
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        note(f"warmup step {i} done in {time.perf_counter() - t_w:.2f} s "
+             f"(peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)")
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        samples = B * world * args.steps
+        line = {
+            "metric": "samples/sec (128x128x512 meas) fwd+bwd" if args.workload == "t512"
+                      else f"samples/sec ({N}x{N}x{T} meas) fwd+bwd",
+            "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
+                                   f"batch {B}/GPU, fp32, random-init weights", "global_batch": B * world,
+                       "parallelism": f"dp{world}", "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
+                       "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
+            "loss": round(float(loss.item()), 6),
+        }
+        roof = None
+        if prof:
+            name, (n, ms) = max(prof.items(), key=lambda kv: kv[1][1])
+            work = algorithmic_work(name, T, N, B)
+            if work and n:
+                bound, amount = work
+                avg_s = ms / n / 1e3
+                if bound == "hbm":
+                    ach, peak, unit = amount / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+                else:
+                    ach, peak, unit = amount / avg_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+                roof = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "traffic": None, "launches": n,
+                        "avg_launch_us": round(1e3 * ms / n, 2)}
+            line["hip_kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}
+        line["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

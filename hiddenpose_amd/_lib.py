@@ -25,6 +25,10 @@ _vp, _fp, _i, _sz, _d = C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_double
 SIGNATURES = {
     "hp_version": (_i, []),
     "hp_last_error_string": (C.c_char_p, []),
+    "hp_profile_enable": (_i, [_i]),
+    "hp_profile_reset": (_i, []),
+    "hp_profile_count": (_i, []),
+    "hp_profile_get": (_i, [_i, C.c_char_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "hp_lct_host_constants": (_i, [_i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hp_lct_plan_create": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i]),
     "hp_lct_plan_destroy": (_i, [_vp]),
@@ -44,6 +48,11 @@ def lib() -> C.CDLL:
                     raise HiddenPoseHipError(
                         f"{LIB_PATH} is missing: the HIP extension is required (no fallback path). "
                         "Build it with `python -m hiddenpose_amd.build`.")
+                # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be in the
+                # process BEFORE this library so that both share ONE HIP runtime; loading the
+                # system runtime first and torch's second leaves the second without devices.
+                import torch  # noqa: F401
+
                 dll = C.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(dll, name)  # AttributeError here = header/library mismatch
@@ -72,3 +81,24 @@ def current_stream_handle(device=None) -> int:
     import torch
 
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def profile_enable(on: bool) -> None:
+    lib().hp_profile_enable(1 if on else 0)
+
+
+def profile_reset() -> None:
+    lib().hp_profile_reset()
+
+
+def profile_read() -> dict:
+    """{kernel name: (launches, total_ms)} of the HIP-event timings recorded since the last reset."""
+    out = {}
+    L = lib()
+    for i in range(L.hp_profile_count()):
+        buf = C.create_string_buffer(128)
+        n = C.c_int64()
+        ms = C.c_double()
+        check(L.hp_profile_get(i, buf, 128, C.byref(n), C.byref(ms)), "hp_profile_get")
+        out[buf.value.decode()] = (int(n.value), float(ms.value))
+    return out

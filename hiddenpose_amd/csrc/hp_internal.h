@@ -29,6 +29,17 @@ void set_error(const char* fmt, ...);
     }                                  \
   } while (0)
 
+// Optional per-kernel timing with HIP events on the launch stream (hp_profile_* in the C ABI).
+// Disabled by default: one relaxed atomic load per launch.
+struct ProfScope {
+  ProfScope(const char* name, hipStream_t st);
+  ~ProfScope();
+  int slot = -1;
+  hipStream_t st = nullptr;
+  hipEvent_t stop = nullptr;
+};
+#define HP_PROF(name, stream) ::hp::ProfScope _hp_prof_scope(name, stream)
+
 inline int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;

@@ -422,6 +422,7 @@ template <int L, bool REAL_IN>
 static void launch_fwd(dim3 grid, hipStream_t st, const float* xr, const float2* in, float2* out, int batch, long vol,
                        PassGeom g, const float2* tw, const float2* hs, const BandDev& b) {
   constexpr int WT = tile_width(L);
+  HP_PROF(REAL_IN ? "lct_axis_fwd_t" : "lct_axis_fwd_h", st);
   hipLaunchKernelGGL((k_axis_fwd<L, WT, REAL_IN>), grid, dim3(NT), 0, st, xr, in, out, batch, vol, g, tw, hs, b.off,
                      b.idx, b.val);
 }
@@ -429,6 +430,7 @@ template <int L, bool REAL_OUT>
 static void launch_inv(dim3 grid, hipStream_t st, const float2* in, float2* out, float* yr, int batch, long vol,
                        PassGeom g, const float2* tw, const float2* hs, const BandDev& b) {
   constexpr int WT = tile_width(L);
+  HP_PROF(REAL_OUT ? "lct_axis_inv_t" : "lct_axis_inv_h", st);
   hipLaunchKernelGGL((k_axis_inv<L, WT, REAL_OUT>), grid, dim3(NT), 0, st, in, out, yr, batch, vol, g, tw, hs, b.off,
                      b.idx, b.val);
 }
@@ -436,6 +438,7 @@ template <int L>
 static void launch_mid(dim3 grid, hipStream_t st, float2* data, const float2* H, long pair_stride, long rows,
                        int conj_h, const float2* tw, const float2* hs) {
   constexpr int RT = tile_width(L);
+  HP_PROF("lct_axis_mid_w", st);
   hipLaunchKernelGGL((k_axis_mid<L, RT>), grid, dim3(NT), 0, st, data, H, pair_stride, rows, conj_h, tw, hs);
 }
 

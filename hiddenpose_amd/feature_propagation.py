@@ -137,3 +137,10 @@ class FeaturePropagation(nn.Module):
 
     def forward(self, x, time_begin=None, time_end=None):
         return self.method(x, time_begin, time_end)
+
+
+def normalize_feature(data_bxcxdxhxw):
+    """models/feature_propagation.py:273-286 (no ReLU: its result is discarded on :274)."""
+    from . import hip_ops
+
+    return hip_ops.normalize_feature(data_bxcxdxhxw)

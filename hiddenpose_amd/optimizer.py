@@ -1,0 +1,12 @@
+"""models/optimizer.py:9-24 `get_optimizer`: Adam(lr) for cfg.TRAIN.OPTIMIZER == 'adam'
+(the reference's SGD branch reads cfg keys that do not exist, so only Adam is live)."""
+from torch import optim
+
+
+def get_optimizer(cfg, model):
+    if cfg.TRAIN.OPTIMIZER == "adam":
+        return optim.Adam(model.parameters(), lr=cfg.TRAIN.LR)
+    if cfg.TRAIN.OPTIMIZER == "sgd":
+        return optim.SGD(model.parameters(), lr=cfg.TRAIN.LR, momentum=getattr(cfg.TRAIN, "MOMENTUM", 0.9),
+                         weight_decay=getattr(cfg.TRAIN, "WD", 0.0), nesterov=getattr(cfg.TRAIN, "NESTEROV", False))
+    return None

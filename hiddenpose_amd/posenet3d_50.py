@@ -1,0 +1,106 @@
+"""3-D ResNet-50 + deconvolution head: the pose regressor of NlosPose.
+
+Drop-in for models/posenet3d_50.py: `get_pose_net_50()` (:308-318) builds
+ResNet(Bottleneck, [3,4,6,3]) with a 7^3 stride-1 single-channel stem, BatchNorm3d,
+MaxPool3d(3,2,1), shortcut type 'B', and DeconvHead(2048, 3 x ConvTranspose3d(k4,s2,p1)
+-> 256, final 1^3 conv -> 24) (:98-153, :156-270).  Same state_dict keys and init.
+(B,1,T,H,W) -> (B,24,T/2,H/2,W/2).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import hip_ops as ops
+
+LAYERS = (3, 4, 6, 3)
+PLANES = (64, 128, 256, 512)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv3d(in_planes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = nn.Conv3d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        o = ops.conv_bn_act(o, self.conv2, self.bn2, relu=True)
+        if self.downsample is not None:
+            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        else:
+            res = x
+        return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res)
+
+
+class DeconvHead(nn.Module):
+    def __init__(self, in_channels, num_layers, num_filters, kernel_size, conv_kernel_size, num_joints):
+        super().__init__()
+        assert kernel_size == 4 and conv_kernel_size == 1
+        self.features = nn.ModuleList()
+        for i in range(num_layers):
+            cin = in_channels if i == 0 else num_filters
+            self.features.append(nn.ConvTranspose3d(cin, num_filters, 4, stride=2, padding=1, bias=False))
+            self.features.append(nn.BatchNorm3d(num_filters))
+            self.features.append(nn.Identity())
+        self.features.append(nn.Conv3d(num_filters, num_joints, 1, bias=True))
+        for m in self.modules():
+            if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
+                nn.init.normal_(m.weight, mean=0, std=0.001)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        f = self.features
+        for i in range(0, len(f) - 1, 3):
+            x = ops.deconv_bn_relu(x, f[i], f[i + 1])
+        return ops.conv3d(x, f[-1].weight, f[-1].bias)
+
+
+class ResNet(nn.Module):
+    def __init__(self, n_input_channels=1):
+        super().__init__()
+        _lib.lib()
+        self.in_planes = 64
+        self.conv1 = nn.Conv3d(n_input_channels, 64, 7, stride=1, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm3d(64)
+        self.layer1 = self._make_layer(PLANES[0], LAYERS[0], 1)
+        self.layer2 = self._make_layer(PLANES[1], LAYERS[1], 2)
+        self.layer3 = self._make_layer(PLANES[2], LAYERS[2], 2)
+        self.layer4 = self._make_layer(PLANES[3], LAYERS[3], 2)
+        self.head = DeconvHead(2048, 3, 256, 4, 1, 24)
+        # reference init order (:207-214): the kaiming pass also overrides the head's 1^3 conv
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        ds = None
+        if stride != 1 or self.in_planes != planes * 4:
+            ds = nn.Sequential(nn.Conv3d(self.in_planes, planes * 4, 1, stride=stride, bias=False),
+                               nn.BatchNorm3d(planes * 4))
+        layers = [Bottleneck(self.in_planes, planes, stride, ds)]
+        self.in_planes = planes * 4
+        layers += [Bottleneck(self.in_planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = ops.stem_conv_bn_relu_pool(x, self.conv1, self.bn1)
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.head(x)
+
+
+def get_pose_net_50():
+    return ResNet(n_input_channels=1)

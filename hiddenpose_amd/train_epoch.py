@@ -1,0 +1,78 @@
+"""Training / evaluation callers of the NlosPose hot path.
+
+Counterpart of utils/train_epoch.py:32-104 (inner loop), train.py:97-229 (seed 410,
+Adam 1e-3, MultiStepLR([2,4,13], 0.2) stepped BEFORE each epoch, checkpoint dict) and
+test.py:138-238 (eval = model.eval() + soft-argmax decode).  Host I/O of the reference
+loop (np.savetxt every step, matplotlib dumps, per-step loss.item() sync) is not part of
+the hot path and is left to the caller.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from .criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
+from .optimizer import get_optimizer
+
+
+def seed_everything(seed: int = 410) -> None:
+    """train.py:89-98"""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def build_training(cfg, model):
+    """Losses, optimiser and schedule exactly as train.py:129-141."""
+    criterion = L2JointLocationLoss(output_3d=True)
+    voxel_criterion = BCEDiceLoss()
+    optimizer = get_optimizer(cfg, model)
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, cfg.TRAIN.LR_STEP, cfg.TRAIN.LR_FACTOR)
+    return criterion, voxel_criterion, optimizer, scheduler
+
+
+def compute_loss(model, criterion, voxel_criterion, meas, vol, target_joints):
+    """train_epoch.py:38-44.  target_joints (B,24,3) or (B,72) in heat-map voxels."""
+    output, feature = model(meas)
+    b = output.shape[0]
+    tj = target_joints.reshape(b, -1)
+    joint_loss = criterion(output, tj, torch.ones_like(tj))
+    voxel_loss = voxel_criterion(feature.reshape(b, -1), vol.reshape(b, -1))
+    return joint_loss + voxel_loss, joint_loss, voxel_loss, output, feature
+
+
+def train_step(model, criterion, voxel_criterion, optimizer, meas, vol, target_joints, reducer=None):
+    """One iteration of train_epoch.py:32-76: forward, loss, zero_grad, backward, step.
+    With a GradBucketReducer the gradient all-reduce overlaps backward."""
+    loss, jl, vl, _, _ = compute_loss(model, criterion, voxel_criterion, meas, vol, target_joints)
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad()
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step()
+    return loss.detach(), jl.detach(), vl.detach()
+
+
+def checkpoint_dict(model, optimizer, lr_scheduler, epoch, global_iter_num=None):
+    """train.py:210-220 / train_epoch.py:78-90 checkpoint layout (test.py:133-136 needs all three)."""
+    d = {"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+         "lr_scheduler": lr_scheduler.state_dict(), "epoch": epoch}
+    if global_iter_num is not None:
+        d["global_iter_num"] = global_iter_num
+    return d
+
+
+@torch.no_grad()
+def predict_joints(model, meas, cfg):
+    """test.py:156-157: eval-mode forward + soft-argmax decode -> (B, 72) voxel coordinates."""
+    model.eval()
+    output, _ = model(meas)
+    hm = cfg.DATASET.HEATMAP_SIZE
+    return softmax_integral_tensor(output, cfg.DATASET.NUM_JOINTS, True, hm[0], hm[1], hm[2])

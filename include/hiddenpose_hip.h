@@ -40,6 +40,14 @@ typedef enum hp_status {
 int hp_version(void);
 const char* hp_last_error_string(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (off by default).
+ * hp_profile_get(i, ...) synchronises the recorded events and returns the launch count
+ * and total milliseconds of the i-th kernel name seen since hp_profile_reset(). */
+int hp_profile_enable(int on);
+int hp_profile_reset(void);
+int hp_profile_count(void);
+int hp_profile_get(int i, char* name, int name_cap, int64_t* launches, double* total_ms);
+
 /* ------------------------------------------------------------------------
  * LCT physics layer.
  * Replaces models/feature_propagation.py: LCT._parpareparam :71-109,

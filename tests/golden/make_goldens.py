@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: consts lct parts posenet e2e e2e128 softargmax   (default: all)
+Sections: schema consts lct parts posenet e2e e2e128 softargmax   (default: all)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
 its filler keyed by state_dict name, so tests rebuild identical inputs and
@@ -287,7 +287,22 @@ def sec_softargmax():
     save("softargmax.npz", demo_pred=pred.numpy(), demo_loss=np.float64(loss.item()), rand_pred=rp.numpy())
 
 
-SECTIONS = {"consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
+def sec_schema():
+    """state_dict key names and shapes of the reference NlosPose (checkpoint contract)."""
+    import json
+
+    from models.NlosPose import NlosPose
+
+    model = NlosPose(ref_shims.make_cfg(32, 32, BIN_LEN[(32, 32)]))
+    sd = model.state_dict()
+    schema = {k: list(v.shape) for k, v in sd.items()}
+    with open(os.path.join(HERE, "state_dict_schema.json"), "w") as f:
+        json.dump(schema, f, indent=0, sort_keys=False)
+    print(f"  wrote state_dict_schema.json: {len(schema)} tensors, "
+          f"{sum(int(np.prod(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k)} parameters")
+
+
+SECTIONS = {"schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "softargmax": sec_softargmax}
 
 if __name__ == "__main__":
