@@ -1,0 +1,641 @@
+// 3-D convolution engine of the pose regressor (posenet3d_50) on gfx950.
+//
+// All activations inside the regressor are channels-last fp32: X[b][d][h][w][C].
+// Every convolution flavour of models/posenet3d_50.py -- 1^3 / 3^3 / 7^3 Conv3d, stride 1
+// or 2, ConvTranspose3d(k4,s2,p1), and all their data / weight gradients -- is ONE
+// implicit GEMM  out[m][n] = sum_k A[m][k] * W[k][n]  with
+//     m = an output voxel of one "class" (a parity class for the stride-2 scatter cases),
+//     k = (tap, input channel),  n = output channel,
+// computed on the matrix cores with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-equal to
+// an fmaf chain, no reduced precision).  A is never materialised: each 128x32 A tile is
+// gathered straight from the channels-last input (128-byte contiguous channel runs per
+// voxel) into LDS; W is pre-packed [tap][n][c] so both operands are K-contiguous.
+//
+// Workgroup = 256 threads = 4 waves; block tile 128(M) x BN(N) x 32(K), each wave owns
+// 32x32 MFMA tiles (2x2 for BN=128).  LDS rows are padded to 33 floats so that the
+// per-lane fragment reads (32 consecutive rows, fixed k) and the staging writes are
+// bank-conflict free.  Global loads of tile t+1 are issued before the MFMAs of tile t.
+// Epilogue: optional bias, per-channel sum / sum-of-squares for train-mode BatchNorm
+// (fp64 atomics, one pair per column per block), 128-byte coalesced channels-last stores.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "hp_internal.h"
+
+namespace hp {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum IgemmMode { MODE_CONV = 0, MODE_DECONV = 1, MODE_DGRAD_S2K3 = 2, MODE_STEM = 3 };
+
+struct IgemmGeom {
+  int mode;
+  int B, Di, Hi, Wi, Cin;  // gathered tensor (channels-last); Cin = K extent per tap
+  int Do, Ho, Wo, Nout;    // written tensor (channels-last)
+  int gd, gh, gw;          // per-class grid of M positions
+  int os;                  // written position = g*os + class parity
+  int k, s, p, flip;       // MODE_CONV: gathered pos = g*s + (flip ? p - kk : kk - p)
+  long M;                  // B*gd*gh*gw
+  int kpt;                 // K tiles per tap (Cin/32, or padded taps/32 for the stem)
+};
+
+constexpr int BM = 128, BK = 32, LDK = BK + 1, CT = 256;
+
+__host__ __device__ inline int class_ntaps(const IgemmGeom& g, int cls) {
+  switch (g.mode) {
+    case MODE_CONV: return g.k * g.k * g.k;
+    case MODE_DECONV: return 8;
+    case MODE_DGRAD_S2K3: return (1 + ((cls >> 2) & 1)) * (1 + ((cls >> 1) & 1)) * (1 + (cls & 1));
+    default: return 1;
+  }
+}
+
+// input offset (relative to g*s) and weight slab of tap `t` of class `cls`
+__device__ __forceinline__ void tap_info(const IgemmGeom& g, int cls, int t, int& dz, int& dy, int& dx, int& widx) {
+  if (g.mode == MODE_CONV) {
+    const int kk = g.k;
+    const int a = t / (kk * kk), b = (t / kk) % kk, c = t % kk;
+    dz = g.flip ? g.p - a : a - g.p;
+    dy = g.flip ? g.p - b : b - g.p;
+    dx = g.flip ? g.p - c : c - g.p;
+    widx = t;
+  } else if (g.mode == MODE_DECONV) {
+    // out[2g+p] = sum_j x[g + p - j] * w[(1-p) + 2j],  j in {0,1}  (k4, s2, p1)
+    const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int jd = (t >> 2) & 1, jh = (t >> 1) & 1, jw = t & 1;
+    dz = pd - jd;
+    dy = ph - jh;
+    dx = pw - jw;
+    widx = (((1 - pd) + 2 * jd) * 4 + ((1 - ph) + 2 * jh)) * 4 + ((1 - pw) + 2 * jw);
+  } else {  // MODE_DGRAD_S2K3: dX[2g+p] = p ? dY[g+1] w[0] + dY[g] w[2] : dY[g] w[1]
+    const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int nw = 1 + pw, nh = 1 + ph;
+    const int jw = t % nw, jh = (t / nw) % nh, jd = t / (nw * nh);
+    const int kd = pd ? 2 * jd : 1, kh = ph ? 2 * jh : 1, kw = pw ? 2 * jw : 1;
+    dz = pd ? 1 - jd : 0;
+    dy = ph ? 1 - jh : 0;
+    dx = pw ? 1 - jw : 0;
+    widx = (kd * 3 + kh) * 3 + kw;
+  }
+}
+
+template <int BN>
+struct TileCfg {
+  static constexpr int WN = BN >= 64 ? 2 : 1;       // waves along N
+  static constexpr int WM = 4 / WN;                 // waves along M
+  static constexpr int TM = BM / (WM * 32);         // 32x32 tiles per wave along M
+  static constexpr int TN = BN / (WN * 32);
+};
+
+template <int BN, bool STEM, bool STATS>
+__global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
+                                              const float* __restrict__ bias, float* __restrict__ Y,
+                                              double* __restrict__ stats, IgemmGeom g) {
+  using C = TileCfg<BN>;
+  __shared__ float As[BM * LDK];
+  __shared__ float Bs[BN * LDK];
+  __shared__ float red[STATS ? 2 * BN * C::WM : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int cls = blockIdx.z;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+
+  // ---- per-thread gather rows: r0 + 32 i
+  const int kq = tid & 7, r0 = tid >> 3;
+  int rb[4], rz[4], ry[4], rx[4];
+  bool rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + r0 + 32 * i;
+    rv[i] = m < g.M;
+    long t = rv[i] ? m : 0;
+    rx[i] = (int)(t % g.gw) * g.s;
+    t /= g.gw;
+    ry[i] = (int)(t % g.gh) * g.s;
+    t /= g.gh;
+    rz[i] = (int)(t % g.gd) * g.s;
+    rb[i] = (int)(t / g.gd);
+  }
+  const int ntaps = STEM ? 1 : class_ntaps(g, cls);
+  const int KT = ntaps * g.kpt;
+
+  float4 ra[4], rbw[BN / 32];
+  auto load_tile = [&](int kt) {
+    if constexpr (STEM) {
+      // single input channel, 7^3 taps spread along K: element (row, kk) = x[voxel + off(kk)]
+      const int kbase = kt * BK + kq * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = kbase + j;
+          const int a = kk / 49, b = (kk / 7) % 7, c = kk % 7;
+          const int z = rz[i] + a - 3, y = ry[i] + b - 3, x = rx[i] + c - 3;
+          const bool ok = rv[i] && kk < 343 && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi &&
+                          (unsigned)x < (unsigned)g.Wi;
+          v[j] = ok ? X[(((long)rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x] : 0.f;
+        }
+        ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        rbw[i] = n < g.Nout ? *(const float4*)(Wp + (long)n * (g.kpt * BK) + kbase) : make_float4(0, 0, 0, 0);
+      }
+    } else {
+      const int tap = kt / g.kpt, c0 = (kt - tap * g.kpt) * BK + kq * 4;
+      int dz, dy, dx, widx;
+      tap_info(g, cls, tap, dz, dy, dx, widx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int z = rz[i] + dz, y = ry[i] + dy, x = rx[i] + dx;
+        const bool ok = rv[i] && c0 < g.Cin && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi &&
+                        (unsigned)x < (unsigned)g.Wi;
+        ra[i] = ok ? *(const float4*)(X + ((((long)rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x) * g.Cin + c0)
+                   : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        rbw[i] = (n < g.Nout && c0 < g.Cin) ? *(const float4*)(Wp + ((long)widx * g.Nout + n) * g.Cin + c0)
+                                            : make_float4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* d = As + (r0 + 32 * i) * LDK + kq * 4;
+      d[0] = ra[i].x;
+      d[1] = ra[i].y;
+      d[2] = ra[i].z;
+      d[3] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      float* d = Bs + (r0 + 32 * i) * LDK + kq * 4;
+      d[0] = rbw[i].x;
+      d[1] = rbw[i].y;
+      d[2] = rbw[i].z;
+      d[3] = rbw[i].w;
+    }
+  };
+
+  f32x16 acc[C::TM][C::TN];
+#pragma unroll
+  for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const float* ap = As + (wm * C::TM * 32 + (lane & 31)) * LDK + (lane >> 5);
+  const float* bp = Bs + (wn * C::TN * 32 + (lane & 31)) * LDK + (lane >> 5);
+  // kt = -1 is the prologue: one call site for the gather keeps the pipeline uniform
+  for (int kt = -1; kt < KT; ++kt) {
+    if (kt + 1 < KT) load_tile(kt + 1);
+    if (kt >= 0) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float a[C::TM], b[C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) a[i] = ap[i * 32 * LDK + 2 * kk];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) b[j] = bp[j * 32 * LDK + 2 * kk];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    if (kt + 1 < KT) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue
+  const bool dense_out = (g.os == 1 && g.gd == g.Do && g.gh == g.Ho && g.gw == g.Wo);
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const long m = m0 + row;
+      if (m >= g.M) continue;
+      long orow = m;
+      if (!dense_out) {
+        long t = m;
+        const int x = (int)(t % g.gw);
+        t /= g.gw;
+        const int y = (int)(t % g.gh);
+        t /= g.gh;
+        const int z = (int)(t % g.gd);
+        const int b = (int)(t / g.gd);
+        orow = (((long)b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw;
+      }
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        const int n = n0 + wn * C::TN * 32 + j * 32 + (lane & 31);
+        if (n < g.Nout) Y[orow * g.Nout + n] = acc[i][j][r] + (bias ? bias[n] : 0.f);
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // column sums over this block's rows (rows past M hold exact zeros)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lane < 32) {
+        const int col = wn * C::TN * 32 + j * 32 + lane;
+        red[(wm * BN + col) * 2 + 0] = s;
+        red[(wm * BN + col) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < g.Nout) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < C::WM; ++w) {
+          s += (double)red[(w * BN + tid) * 2 + 0];
+          q += (double)red[(w * BN + tid) * 2 + 1];
+        }
+        atomicAdd(stats + n, s);
+        atomicAdd(stats + g.Nout + n, q);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dW[slab][n][c] += sum_m dY[orow(m)][n] * X[gather(m, tap)][c]   (reduction over voxels)
+// A = dY^T tile, B = gathered X tile; both are staged exactly as they lie in memory
+// ([m][channel]), which is already the conflict-free MFMA fragment order.  The voxel range
+// is split over blockIdx.z; partial tiles are combined with fp32 atomics.
+constexpr int WG_T = 64;   // dW tile: 64 (n) x 64 (c)
+constexpr int WG_KM = 32;  // voxels per step
+
+template <bool STEM>
+__global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
+                                              float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit,
+                                              int ntap_total) {
+  __shared__ float Ys[WG_KM * WG_T];
+  __shared__ float Xs[WG_KM * WG_T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_n = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  const int n0 = tile_n * WG_T, c0 = tile_c * WG_T;
+  // blockIdx.y enumerates (class, tap)
+  int cls = 0, tap = blockIdx.y;
+  if (!STEM) {
+    while (tap >= class_ntaps(g, cls)) {
+      tap -= class_ntaps(g, cls);
+      ++cls;
+    }
+  }
+  (void)ntap_total;
+  const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+  int dz = 0, dy = 0, dx = 0, widx = 0;
+  if (!STEM) tap_info(g, cls, tap, dz, dy, dx, widx);
+  const long chunk = ((g.M + msplit - 1) / msplit + WG_KM - 1) / WG_KM * WG_KM;
+  const long mbeg = (long)blockIdx.z * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
+  const int Kc = STEM ? g.kpt * BK : g.Cin;  // extent of the c axis
+
+  // staging: 32 rows x 64 floats = 512 float4 -> 2 per thread for each operand
+  const int sr = tid >> 4, sq = tid & 15;  // rows sr, sr+16 ; float4 column sq
+  // wave tile: 2x2 waves of 32x32
+  const int wn = wave >> 1, wc = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (long mb = mbeg; mb < mend; mb += WG_KM) {
+    float4 vy[2], vx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long m = mb + sr + 16 * h;
+      vy[h] = make_float4(0, 0, 0, 0);
+      vx[h] = make_float4(0, 0, 0, 0);
+      if (m < mend) {
+        long t = m;
+        const int x = (int)(t % g.gw);
+        t /= g.gw;
+        const int y = (int)(t % g.gh);
+        t /= g.gh;
+        const int z = (int)(t % g.gd);
+        const int b = (int)(t / g.gd);
+        const long orow = (((long)b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw;
+        const int n = n0 + sq * 4;
+        if (n + 3 < g.Nout) {
+          vy[h] = *(const float4*)(dY + orow * g.Nout + n);
+        } else {
+          float t4[4] = {0, 0, 0, 0};
+          for (int e = 0; e < 4; ++e)
+            if (n + e < g.Nout) t4[e] = dY[orow * g.Nout + n + e];
+          vy[h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+        if constexpr (STEM) {
+          float t4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kk = c0 + sq * 4 + e;
+            const int a = kk / 49, bb = (kk / 7) % 7, cc = kk % 7;
+            const int zz = z + a - 3, yy = y + bb - 3, xx = x + cc - 3;
+            const bool ok = kk < 343 && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi &&
+                            (unsigned)xx < (unsigned)g.Wi;
+            t4[e] = ok ? X[(((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx] : 0.f;
+          }
+          vx[h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        } else {
+          const int zz = z * g.s + dz, yy = y * g.s + dy, xx = x * g.s + dx;
+          const int c = c0 + sq * 4;
+          if ((unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
+              c < g.Cin)
+            vx[h] = *(const float4*)(X + ((((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
+        }
+      }
+    }
+    __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *(float4*)(Ys + (sr + 16 * h) * WG_T + sq * 4) = vy[h];
+      *(float4*)(Xs + (sr + 16 * h) * WG_T + sq * 4) = vx[h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < WG_KM / 2; ++kk) {
+      const int mrow = 2 * kk + (lane >> 5);
+      const float a = Ys[mrow * WG_T + wn * 32 + (lane & 31)];
+      const float b = Xs[mrow * WG_T + wc * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // dW layout: [slab][n][Kc]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (n < g.Nout && c < Kc) atomicAdd(dW + ((long)widx * g.Nout + n) * Kc + c, acc[r]);
+  }
+}
+
+// ---------------------------------------------------------------- weight (un)packing
+// torch Conv3d weight (Cout,Cin,k,k,k)  <->  packed [tap][Cout][Cin]   (transposed=0)
+// torch ConvTranspose3d weight (Cin,Cout,k,k,k) <-> packed [tap][Cout][Cin]   (transposed=1)
+// `swap` writes [tap][Cin][Cout] instead (operand of the data-gradient GEMM).
+__global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int taps,
+                              int transposed, int swap, int to_torch) {
+  const long total = (long)Cout * Cin * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // i enumerates the packed layout
+    const int inner = (int)(i % (swap ? Cout : Cin));
+    long r = i / (swap ? Cout : Cin);
+    const int outer = (int)(r % (swap ? Cin : Cout));
+    const int t = (int)(r / (swap ? Cin : Cout));
+    const int co = swap ? inner : outer, ci = swap ? outer : inner;
+    const long ti = transposed ? ((long)ci * Cout + co) * taps + t : ((long)co * Cin + ci) * taps + t;
+    if (to_torch)
+      ((float*)w)[ti] = out[i];
+    else
+      out[i] = w[ti];
+  }
+}
+
+// stem: torch (64,1,7,7,7) <-> [64][kpad] (taps along K, zero padded)
+__global__ void k_pack_stem(const float* __restrict__ w, float* __restrict__ out, int Cout, int kpad, int to_torch) {
+  const long total = (long)Cout * kpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % kpad), n = (int)(i / kpad);
+    if (to_torch) {
+      if (k < 343) ((float*)w)[(long)n * 343 + k] = out[i];
+    } else {
+      out[i] = k < 343 ? w[(long)n * 343 + k] : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host dispatch
+struct ConvPlan {
+  IgemmGeom fwd, dgrad, wgrad;
+  int fwd_classes = 1, dgrad_classes = 1, wgrad_tapsum = 1;
+  bool stem = false, dgrad_zero_fill = false;
+};
+
+static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
+  HP_REQUIRE(d.B >= 1 && d.Cin >= 1 && d.Cout >= 1, "conv: bad channel/batch sizes");
+  const int k = d.k, s = d.stride, pad = d.pad;
+  IgemmGeom f{};
+  if (!d.transposed) {
+    const int Do = (d.Di + 2 * pad - k) / s + 1, Ho = (d.Hi + 2 * pad - k) / s + 1, Wo = (d.Wi + 2 * pad - k) / s + 1;
+    p.stem = (d.Cin == 1 && k == 7 && s == 1 && pad == 3);
+    if (!p.stem) HP_REQUIRE(d.Cin % 4 == 0, "conv: Cin must be a multiple of 4 (got %d)", d.Cin);
+    HP_REQUIRE(s == 1 || s == 2, "conv: stride must be 1 or 2");
+    const int kpt = p.stem ? (343 + 31) / 32 : (d.Cin + 31) / 32;
+    f = IgemmGeom{p.stem ? MODE_STEM : MODE_CONV, d.B, d.Di, d.Hi, d.Wi, d.Cin, Do, Ho, Wo, d.Cout, Do, Ho, Wo, 1,
+                  k, s, pad, 0, (long)d.B * Do * Ho * Wo, kpt};
+    p.fwd = f;
+    p.fwd_classes = 1;
+    // weight gradient: same gather as forward
+    p.wgrad = f;
+    p.wgrad_tapsum = p.stem ? 1 : k * k * k;
+    // data gradient
+    IgemmGeom g{};
+    if (p.stem) {
+      // gradient w.r.t. the single-channel volume: N = 1 (correct, but 1/32 of the MFMA tile is used)
+      g = IgemmGeom{MODE_CONV, d.B, Do, Ho, Wo, d.Cout, d.Di, d.Hi, d.Wi, 1, d.Di, d.Hi, d.Wi, 1,
+                    7, 1, 3, 1, (long)d.B * d.Di * d.Hi * d.Wi, d.Cout / 32};
+      p.dgrad_classes = 1;
+    } else if (s == 1) {
+      HP_REQUIRE(d.Cout % 4 == 0, "conv dgrad: Cout must be a multiple of 4 (got %d)", d.Cout);
+      g = IgemmGeom{MODE_CONV, d.B, Do, Ho, Wo, d.Cout, d.Di, d.Hi, d.Wi, d.Cin, d.Di, d.Hi, d.Wi, 1,
+                    k, 1, pad, 1, (long)d.B * d.Di * d.Hi * d.Wi, (d.Cout + 31) / 32};
+      p.dgrad_classes = 1;
+    } else if (k == 3 && pad == 1) {
+      HP_REQUIRE(d.Di % 2 == 0 && d.Hi % 2 == 0 && d.Wi % 2 == 0 && d.Cout % 32 == 0, "conv dgrad s2: even dims needed");
+      g = IgemmGeom{MODE_DGRAD_S2K3, d.B, Do, Ho, Wo, d.Cout, d.Di, d.Hi, d.Wi, d.Cin, d.Di / 2, d.Hi / 2, d.Wi / 2, 2,
+                    3, 1, 1, 0, (long)d.B * (d.Di / 2) * (d.Hi / 2) * (d.Wi / 2), d.Cout / 32};
+      p.dgrad_classes = 8;
+    } else if (k == 1 && pad == 0) {
+      HP_REQUIRE(d.Di % 2 == 0 && d.Hi % 2 == 0 && d.Wi % 2 == 0 && d.Cout % 32 == 0, "conv dgrad s2: even dims needed");
+      g = IgemmGeom{MODE_CONV, d.B, Do, Ho, Wo, d.Cout, d.Di, d.Hi, d.Wi, d.Cin, Do, Ho, Wo, 2,
+                    1, 1, 0, 0, (long)d.B * Do * Ho * Wo, d.Cout / 32};
+      p.dgrad_classes = 1;
+      p.dgrad_zero_fill = true;
+    } else {
+      set_error("conv: unsupported stride-2 kernel %d pad %d", k, pad);
+      return HP_ERR_UNSUPPORTED;
+    }
+    p.dgrad = g;
+  } else {
+    HP_REQUIRE(k == 4 && s == 2 && pad == 1, "deconv: only k4 s2 p1 is supported");
+    HP_REQUIRE(d.Cin % 32 == 0 && d.Cout % 32 == 0, "deconv: channels must be multiples of 32");
+    const int Do = 2 * d.Di, Ho = 2 * d.Hi, Wo = 2 * d.Wi;
+    f = IgemmGeom{MODE_DECONV, d.B, d.Di, d.Hi, d.Wi, d.Cin, Do, Ho, Wo, d.Cout, d.Di, d.Hi, d.Wi, 2,
+                  4, 1, 1, 0, (long)d.B * d.Di * d.Hi * d.Wi, d.Cin / 32};
+    p.fwd = f;
+    p.fwd_classes = 8;
+    p.wgrad = f;
+    p.wgrad_tapsum = 64;
+    // dX[i] = sum_k dY[2i - 1 + k] w[k] : a stride-2 k4 p1 gather of dY
+    p.dgrad = IgemmGeom{MODE_CONV, d.B, Do, Ho, Wo, d.Cout, d.Di, d.Hi, d.Wi, d.Cin, d.Di, d.Hi, d.Wi, 1,
+                        4, 2, 1, 0, (long)d.B * d.Di * d.Hi * d.Wi, d.Cout / 32};
+    p.dgrad_classes = 1;
+  }
+  return HP_OK;
+}
+
+template <bool STEM, bool STATS>
+static void launch_igemm_bn(const IgemmGeom& g, int classes, const float* X, const float* W, const float* bias, float* Y,
+                            double* stats, hipStream_t st) {
+  const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  if (g.Nout > 64) {
+    hipLaunchKernelGGL((k_igemm<128, STEM, STATS>), dim3(mt, (g.Nout + 127) / 128, classes), dim3(CT), 0, st, X, W,
+                       bias, Y, stats, g);
+  } else if (g.Nout > 32) {
+    hipLaunchKernelGGL((k_igemm<64, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, g);
+  } else {
+    hipLaunchKernelGGL((k_igemm<32, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, g);
+  }
+}
+
+static void launch_igemm(const IgemmGeom& g, int classes, bool stem, const float* X, const float* W, const float* bias,
+                         float* Y, double* stats, hipStream_t st) {
+  if (stem) {
+    if (stats) launch_igemm_bn<true, true>(g, classes, X, W, bias, Y, stats, st);
+    else launch_igemm_bn<true, false>(g, classes, X, W, bias, Y, stats, st);
+  } else {
+    if (stats) launch_igemm_bn<false, true>(g, classes, X, W, bias, Y, stats, st);
+    else launch_igemm_bn<false, false>(g, classes, X, W, bias, Y, stats, st);
+  }
+}
+
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" size_t hp_conv3d_packed_weight_elems(const hp_conv_desc* d) {
+  if (!d) return 0;
+  if (!d->transposed && d->Cin == 1 && d->k == 7) return (size_t)d->Cout * ((343 + 31) / 32 * 32);
+  return (size_t)d->Cout * d->Cin * d->k * d->k * d->k;
+}
+
+extern "C" int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, float* w_fwd, float* w_dgrad,
+                                     void* stream) {
+  HP_REQUIRE(d && w_torch, "hp_conv3d_pack_weight: null argument");
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int taps = d->k * d->k * d->k;
+  if (p.stem) {
+    const int kpad = p.fwd.kpt * BK;
+    HP_PROF("conv_pack_weight", st);
+    if (w_fwd) hipLaunchKernelGGL(k_pack_stem, dim3(64), dim3(256), 0, st, w_torch, w_fwd, d->Cout, kpad, 0);
+    if (w_dgrad) hipLaunchKernelGGL(k_pack_weight, dim3(64), dim3(256), 0, st, w_torch, w_dgrad, d->Cout, 1, 343, 0, 1, 0);
+  } else {
+    const long total = (long)d->Cout * d->Cin * taps;
+    const unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+    HP_PROF("conv_pack_weight", st);
+    if (w_fwd) hipLaunchKernelGGL(k_pack_weight, dim3(nb), dim3(256), 0, st, w_torch, w_fwd, d->Cout, d->Cin, taps,
+                                  d->transposed, 0, 0);
+    if (w_dgrad) hipLaunchKernelGGL(k_pack_weight, dim3(nb), dim3(256), 0, st, w_torch, w_dgrad, d->Cout, d->Cin, taps,
+                                    d->transposed, 1, 0);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_packed, float* dw_torch, void* stream) {
+  HP_REQUIRE(d && dw_packed && dw_torch, "hp_conv3d_unpack_wgrad: null argument");
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int taps = d->k * d->k * d->k;
+  HP_PROF("conv_pack_weight", st);
+  if (p.stem) {
+    hipLaunchKernelGGL(k_pack_stem, dim3(64), dim3(256), 0, st, dw_torch, (float*)dw_packed, d->Cout, p.fwd.kpt * BK, 1);
+  } else {
+    const long total = (long)d->Cout * d->Cin * taps;
+    const unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_pack_weight, dim3(nb), dim3(256), 0, st, dw_torch, (float*)dw_packed, d->Cout, d->Cin, taps,
+                       d->transposed, 0, 1);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd, const float* bias, float* y,
+                                 double* stats, void* stream) {
+  HP_REQUIRE(d && x && w_fwd && y, "hp_conv3d_forward: null argument");
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
+  {
+    HP_PROF(p.stem ? "conv_igemm_stem" : d->transposed ? "conv_igemm_deconv" : d->k == 1 ? "conv_igemm_k1" : "conv_igemm_k3", st);
+    launch_igemm(p.fwd, p.fwd_classes, p.stem, x, w_fwd, bias, y, stats, st);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                                       void* stream) {
+  HP_REQUIRE(d && dy && w_dgrad && dx, "hp_conv3d_backward_data: null argument");
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.dgrad_zero_fill)
+    HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin, st));
+  {
+    HP_PROF("conv_igemm_dgrad", st);
+    launch_igemm(p.dgrad, p.dgrad_classes, false, dy, w_dgrad, nullptr, dx, nullptr, st);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float* dy, float* dw_packed,
+                                         void* stream) {
+  HP_REQUIRE(d && x && dy && dw_packed, "hp_conv3d_backward_weight: null argument");
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const IgemmGeom& g = p.wgrad;
+  const int Kc = p.stem ? g.kpt * BK : g.Cin;
+  HP_CHECK_HIP(hipMemsetAsync(dw_packed, 0, sizeof(float) * hp_conv3d_packed_weight_elems(d), st));
+  const int tiles_n = (g.Nout + WG_T - 1) / WG_T, tiles_c = (Kc + WG_T - 1) / WG_T;
+  const long base_blocks = (long)tiles_n * tiles_c * p.wgrad_tapsum;
+  long msplit = std::max<long>(1, (2048 + base_blocks - 1) / base_blocks);
+  msplit = std::min<long>(msplit, std::max<long>(1, g.M / (4 * WG_KM)));
+  msplit = std::min<long>(msplit, 4096);
+  dim3 grid((unsigned)(tiles_n * tiles_c), (unsigned)p.wgrad_tapsum, (unsigned)msplit);
+  {
+    HP_PROF("conv_wgrad", st);
+    if (p.stem) hipLaunchKernelGGL((k_wgrad<true>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, p.wgrad_tapsum);
+    else hipLaunchKernelGGL((k_wgrad<false>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, p.wgrad_tapsum);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}

@@ -1,0 +1,394 @@
+// Memory-bound companions of the convolution engine (channels-last fp32, [M][C] matrices):
+// BatchNorm3d train/eval apply with fused residual add + ReLU, its two-pass backward,
+// MaxPool3d(3,2,1) forward/backward, and layout changes at the regressor boundary.
+// All of them stream 16 bytes per lane; per-channel reductions go through LDS and end in
+// one fp64 atomic per channel per block.
+#include <algorithm>
+
+#include "hp_internal.h"
+
+namespace hp {
+
+constexpr int ET = 256;
+
+// stats[0:C] = sum, stats[C:2C] = sum of squares (fp64) over M rows
+__global__ void k_bn_finalize(const double* __restrict__ stats, long M, int C, float eps, float momentum,
+                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                              float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = stats[c] / (double)M;
+  double var = stats[C + c] / (double)M - m * m;
+  if (var < 0) var = 0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+__global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var, int C,
+                                float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// y = act((z - mean) * rstd * gamma + beta [+ res])
+__global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, const float4* __restrict__ res,
+                                                 float4* __restrict__ y, long n4, int C4, const float4* __restrict__ mean,
+                                                 const float4* __restrict__ rstd, const float4* __restrict__ gamma,
+                                                 const float4* __restrict__ beta, int relu) {
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    const float4 v = z[i], m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+    float4 o;
+    o.x = (v.x - m.x) * r.x * g.x + b.x;
+    o.y = (v.y - m.y) * r.y * g.y + b.y;
+    o.z = (v.z - m.z) * r.z * g.z + b.z;
+    o.w = (v.w - m.w) * r.w * g.w + b.w;
+    if (res) {
+      const float4 q = res[i];
+      o.x += q.x;
+      o.y += q.y;
+      o.z += q.z;
+      o.w += q.w;
+    }
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f);
+      o.y = fmaxf(o.y, 0.f);
+      o.z = fmaxf(o.z, 0.f);
+      o.w = fmaxf(o.w, 0.f);
+    }
+    y[i] = o;
+  }
+}
+
+// Pass 1 of the backward: g = dy * [y > 0] (written to g_out), per channel sum(g) and
+// sum(g * zhat) into red[0:C], red[C:2C] (fp64).  Thread t owns channel quad (t % C4) --
+// the block strides over rows so that a thread always sees the same channels.
+__global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                      const float4* __restrict__ z, float4* __restrict__ g_out, long M,
+                                                      int C4, const float4* __restrict__ mean,
+                                                      const float4* __restrict__ rstd, int relu,
+                                                      double* __restrict__ red) {
+  __shared__ float4 ssum[ET], sdot[ET];
+  const int tid = threadIdx.x;
+  const int lanes_per_row = C4 < ET ? C4 : ET;       // threads covering one row pass
+  const int rows_per_pass = ET / lanes_per_row;      // >= 1 when C4 <= ET
+  const int cq_passes = (C4 + ET - 1) / ET;          // > 1 when C4 > ET
+  const int my_row = tid / lanes_per_row, my_cq0 = tid % lanes_per_row;
+  for (int cp = 0; cp < cq_passes; ++cp) {
+    const int cq = my_cq0 + cp * ET;
+    float4 s = make_float4(0, 0, 0, 0), d = make_float4(0, 0, 0, 0);
+    if (cq < C4 && my_row < rows_per_pass) {
+      const float4 m = mean[cq], r = rstd[cq];
+      for (long row = (long)blockIdx.x * rows_per_pass + my_row; row < M; row += (long)gridDim.x * rows_per_pass) {
+        const long i = row * C4 + cq;
+        float4 g = dy[i];
+        if (relu) {
+          const float4 yy = y[i];
+          g.x = yy.x > 0.f ? g.x : 0.f;
+          g.y = yy.y > 0.f ? g.y : 0.f;
+          g.z = yy.z > 0.f ? g.z : 0.f;
+          g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (g_out) g_out[i] = g;
+        const float4 v = z[i];
+        s.x += g.x;
+        s.y += g.y;
+        s.z += g.z;
+        s.w += g.w;
+        d.x += g.x * (v.x - m.x) * r.x;
+        d.y += g.y * (v.y - m.y) * r.y;
+        d.z += g.z * (v.z - m.z) * r.z;
+        d.w += g.w * (v.w - m.w) * r.w;
+      }
+    }
+    ssum[tid] = s;
+    sdot[tid] = d;
+    __syncthreads();
+    if (my_row == 0 && cq < C4) {
+      for (int rr = 1; rr < rows_per_pass; ++rr) {
+        const float4 a = ssum[rr * lanes_per_row + my_cq0], b = sdot[rr * lanes_per_row + my_cq0];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        d.x += b.x; d.y += b.y; d.z += b.z; d.w += b.w;
+      }
+      const int C = C4 * 4;
+      atomicAdd(red + cq * 4 + 0, (double)s.x);
+      atomicAdd(red + cq * 4 + 1, (double)s.y);
+      atomicAdd(red + cq * 4 + 2, (double)s.z);
+      atomicAdd(red + cq * 4 + 3, (double)s.w);
+      atomicAdd(red + C + cq * 4 + 0, (double)d.x);
+      atomicAdd(red + C + cq * 4 + 1, (double)d.y);
+      atomicAdd(red + C + cq * 4 + 2, (double)d.z);
+      atomicAdd(red + C + cq * 4 + 3, (double)d.w);
+    }
+    __syncthreads();
+  }
+}
+
+// dgamma = sum(g zhat), dbeta = sum(g); coefficients of pass 2:
+//   dz = a * g + b * z + c   with  a = gamma rstd, b = -a rstd mean(g zhat), c = -a mean(g) - b mean
+__global__ void k_bn_bwd_coef(const double* __restrict__ red, long M, int C, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ gamma, int train,
+                              float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ca,
+                              float* __restrict__ cb, float* __restrict__ cc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = red[c], sd = red[C + c];
+  if (dgamma) dgamma[c] = (float)sd;
+  if (dbeta) dbeta[c] = (float)sg;
+  const double a = (double)gamma[c] * rstd[c];
+  if (train) {
+    const double b = -a * rstd[c] * (sd / (double)M);
+    ca[c] = (float)a;
+    cb[c] = (float)b;
+    cc[c] = (float)(-a * (sg / (double)M) - b * mean[c]);
+  } else {  // eval mode: statistics are constants
+    ca[c] = (float)a;
+    cb[c] = 0.f;
+    cc[c] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply(const float4* __restrict__ g, const float4* __restrict__ z,
+                                                     float4* __restrict__ dz, long n4, int C4,
+                                                     const float4* __restrict__ ca, const float4* __restrict__ cb,
+                                                     const float4* __restrict__ cc) {
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    const float4 gg = g[i], v = z[i], a = ca[c], b = cb[c], k = cc[c];
+    float4 o;
+    o.x = a.x * gg.x + b.x * v.x + k.x;
+    o.y = a.y * gg.y + b.y * v.y + k.y;
+    o.z = a.z * gg.z + b.z * v.z + k.z;
+    o.w = a.w * gg.w + b.w * v.w + k.w;
+    dz[i] = o;
+  }
+}
+
+// MaxPool3d(kernel 3, stride 2, pad 1), channels-last
+__global__ __launch_bounds__(ET) void k_maxpool3_fwd(const float4* __restrict__ x, float4* __restrict__ y, int B, int D,
+                                                     int H, int W, int C4) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * Do * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do);
+    const int b = (int)(t / Do);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int a = -1; a <= 1; ++a) {
+      const int z = 2 * od + a;
+      if ((unsigned)z >= (unsigned)D) continue;
+      for (int bb = -1; bb <= 1; ++bb) {
+        const int yy = 2 * oh + bb;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int cc = -1; cc <= 1; ++cc) {
+          const int xx = 2 * ow + cc;
+          if ((unsigned)xx >= (unsigned)W) continue;
+          const float4 v = x[((((long)b * D + z) * H + yy) * W + xx) * C4 + c];
+          m.x = fmaxf(m.x, v.x);
+          m.y = fmaxf(m.y, v.y);
+          m.z = fmaxf(m.z, v.z);
+          m.w = fmaxf(m.w, v.w);
+        }
+      }
+    }
+    y[i] = m;
+  }
+}
+
+// gather form of the backward: dx[i] = sum over the <= 8 windows containing i of dy[o] [x[i] == y[o]]
+__global__ __launch_bounds__(ET) void k_maxpool3_bwd(const float4* __restrict__ x, const float4* __restrict__ y,
+                                                     const float4* __restrict__ dy, float4* __restrict__ dx, int B, int D,
+                                                     int H, int W, int C4) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * D * H * W * C4;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    const float4 v = x[i];
+    float4 acc = make_float4(0, 0, 0, 0);
+    // windows o with 2o-1 <= i <= 2o+1  ->  o in {floor(i/2), floor((i+1)/2)} (deduplicated)
+    const int d0 = d / 2, d1 = (d + 1) / 2, h0 = h / 2, h1 = (h + 1) / 2, w0 = w / 2, w1 = (w + 1) / 2;
+    for (int a = 0; a < 2; ++a) {
+      const int od = a ? d1 : d0;
+      if ((a && d1 == d0) || od >= Do) continue;
+      for (int bb = 0; bb < 2; ++bb) {
+        const int oh = bb ? h1 : h0;
+        if ((bb && h1 == h0) || oh >= Ho) continue;
+        for (int cc = 0; cc < 2; ++cc) {
+          const int ow = cc ? w1 : w0;
+          if ((cc && w1 == w0) || ow >= Wo) continue;
+          const long o = ((((long)b * Do + od) * Ho + oh) * Wo + ow) * C4 + c;
+          const float4 m = y[o], g = dy[o];
+          acc.x += v.x == m.x ? g.x : 0.f;
+          acc.y += v.y == m.y ? g.y : 0.f;
+          acc.z += v.z == m.z ? g.z : 0.f;
+          acc.w += v.w == m.w ? g.w : 0.f;
+        }
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// [B][V][C] <-> [B][C][V] through a 32x32 LDS tile
+__global__ void k_transpose_vc(const float* __restrict__ in, float* __restrict__ out, long V, int C, int to_ncv) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const long v0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+  const float* ib = in + (long)b * V * C;
+  float* ob = out + (long)b * V * C;
+  if (to_ncv) {  // in [V][C] -> out [C][V]
+    for (int r = ty; r < 32; r += 8) {
+      const long v = v0 + r;
+      const int c = c0 + tx;
+      t[r][tx] = (v < V && c < C) ? ib[v * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r;
+      const long v = v0 + tx;
+      if (v < V && c < C) ob[(long)c * V + v] = t[tx][r];
+    }
+  } else {  // in [C][V] -> out [V][C]
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r;
+      const long v = v0 + tx;
+      t[r][tx] = (v < V && c < C) ? ib[(long)c * V + v] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const long v = v0 + r;
+      const int c = c0 + tx;
+      if (v < V && c < C) ob[v * C + c] = t[tx][r];
+    }
+  }
+}
+
+static unsigned grid_for(long n, int per_block = ET) {
+  return (unsigned)std::min<long>((n + per_block - 1) / per_block, 256 * 8);
+}
+
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float momentum, float* mean,
+                                    float* rstd, float* running_mean, float* running_var, void* stream) {
+  HP_REQUIRE(stats && mean && rstd && M > 0 && C > 0, "hp_bn_train_finalize: bad argument");
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, M, C, eps, momentum,
+                     mean, rstd, running_mean, running_var);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                                float* rstd, void* stream) {
+  HP_REQUIRE(running_mean && running_var && mean && rstd && C > 0, "hp_bn_eval_stats: bad argument");
+  hipLaunchKernelGGL(k_bn_eval_stats, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, running_mean, running_var,
+                     C, eps, mean, rstd);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int relu, void* stream) {
+  HP_REQUIRE(z && y && mean && rstd && gamma && beta && M > 0 && C > 0 && C % 4 == 0, "hp_bn_apply: bad argument");
+  const long n4 = M * (C / 4);
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("bn_apply", st);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)z, (const float4*)res, (float4*)y, n4,
+                     C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// workspace: 2*C doubles (reduction) + 3*C floats (coefficients)
+extern "C" size_t hp_bn_backward_workspace_bytes(int C) { return sizeof(double) * 2 * C + sizeof(float) * 3 * C; }
+
+extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
+                              const float* mean, const float* rstd, const float* gamma, int relu, int train,
+                              float* dgamma, float* dbeta, void* workspace, void* stream) {
+  HP_REQUIRE(dy && z && dz && mean && rstd && gamma && workspace && M > 0 && C > 0 && C % 4 == 0,
+             "hp_bn_backward: bad argument");
+  HP_REQUIRE(!relu || y, "hp_bn_backward: relu needs the forward output");
+  hipStream_t st = (hipStream_t)stream;
+  double* red = (double*)workspace;
+  float* ca = (float*)(red + 2 * C);
+  float* cb = ca + C;
+  float* cc = cb + C;
+  HP_CHECK_HIP(hipMemsetAsync(red, 0, sizeof(double) * 2 * C, st));
+  const int C4 = C / 4;
+  // g buffer: caller-provided g_out, or dz itself (pass 2 then runs in place)
+  float* gbuf = g_out ? g_out : dz;
+  {
+    HP_PROF("bn_bwd_reduce", st);
+    const int rows_per_pass = C4 < ET ? ET / C4 : 1;
+    const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 4);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(ET), 0, st, (const float4*)dy, (const float4*)y, (const float4*)z,
+                       (float4*)gbuf, M, C4, (const float4*)mean, (const float4*)rstd, relu, red);
+  }
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, M, C, mean, rstd, gamma, train, dgamma,
+                     dbeta, ca, cb, cc);
+  {
+    HP_PROF("bn_bwd_apply", st);
+    const long n4 = M * C4;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)gbuf, (const float4*)z,
+                       (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream) {
+  HP_REQUIRE(x && y && C % 4 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "hp_maxpool3d_k3s2_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("maxpool3_fwd", st);
+  const long n = (long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(k_maxpool3_fwd, dim3(grid_for(n)), dim3(ET), 0, st, (const float4*)x, (float4*)y, B, D, H, W, C / 4);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H,
+                                          int W, int C, void* stream) {
+  HP_REQUIRE(x && y && dy && dx && C % 4 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
+             "hp_maxpool3d_k3s2_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("maxpool3_bwd", st);
+  const long n = (long)B * D * H * W * (C / 4);
+  hipLaunchKernelGGL(k_maxpool3_bwd, dim3(grid_for(n)), dim3(ET), 0, st, (const float4*)x, (const float4*)y,
+                     (const float4*)dy, (float4*)dx, B, D, H, W, C / 4);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_layout_transpose(const float* in, float* out, int B, long V, int C, int to_channels_first,
+                                   void* stream) {
+  HP_REQUIRE(in && out && B > 0 && V > 0 && C > 0, "hp_layout_transpose: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("layout_transpose", st);
+  hipLaunchKernelGGL(k_transpose_vc, dim3((unsigned)((V + 31) / 32), (C + 31) / 32, B), dim3(256), 0, st, in, out, V, C,
+                     to_channels_first);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}

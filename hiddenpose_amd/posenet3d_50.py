@@ -63,7 +63,7 @@ class DeconvHead(nn.Module):
         f = self.features
         for i in range(0, len(f) - 1, 3):
             x = ops.deconv_bn_relu(x, f[i], f[i + 1])
-        return ops.conv3d(x, f[-1].weight, f[-1].bias)
+        return ops.head_conv_to_ncdhw(x, f[-1])
 
 
 class ResNet(nn.Module):

@@ -82,6 +82,57 @@ int hp_lct_backward(const hp_lct_plan* plan, const float* gy, float* gx, int bat
 /* Test hook: copy the device-resident inverse PSF back in natural (2T,2N,2N) order. */
 int hp_lct_plan_get_invpsf(const hp_lct_plan* plan, float* invpsf_re, float* invpsf_im);
 
+/* ------------------------------------------------------------------------
+ * Pose regressor (models/posenet3d_50.py) building blocks.  Activations are
+ * channels-last fp32, X[b][d][h][w][C]; all GEMM arithmetic is exact-fp32 MFMA.
+ *
+ * hp_conv3d_* replace nn.Conv3d / nn.ConvTranspose3d forward and both gradients
+ * (posenet3d_50.py:9-24 conv3x3x3/conv1x1x1, :176-181 stem, :129-132 deconv).
+ * Supported: Conv3d k in {1,3,7}, stride 1|2 (k7: the 1-channel stride-1 stem),
+ * Cin % 32 == 0 otherwise; ConvTranspose3d k4 s2 p1.
+ * Weights are used in a packed K-contiguous layout ([tap][Cout][Cin]; for the
+ * data gradient [tap][Cin][Cout]) produced by hp_conv3d_pack_weight from the
+ * torch layout and converted back for gradients by hp_conv3d_unpack_wgrad.
+ * ---------------------------------------------------------------------- */
+typedef struct hp_conv_desc {
+  int B, Di, Hi, Wi; /* input volume */
+  int Cin, Cout;
+  int k, stride, pad;
+  int transposed; /* 0: Conv3d, 1: ConvTranspose3d */
+} hp_conv_desc;
+
+size_t hp_conv3d_packed_weight_elems(const hp_conv_desc* d);
+int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, float* w_fwd, float* w_dgrad, void* stream);
+int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_packed, float* dw_torch, void* stream);
+/* y = conv(x) [+ bias]; if stats != NULL it receives per-channel sum and sum of squares of y
+ * (2*Cout doubles, zeroed by the call) for train-mode BatchNorm. */
+int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd, const float* bias, float* y,
+                      double* stats, void* stream);
+int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx, void* stream);
+/* dw_packed (same layout as w_fwd) is zeroed and accumulated by the call. */
+int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float* dy, float* dw_packed, void* stream);
+
+/* BatchNorm3d (posenet3d_50.py:70-95,133,182) on [M][C] channels-last matrices. */
+int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float momentum, float* mean, float* rstd,
+                         float* running_mean, float* running_var, void* stream);
+int hp_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
+                     void* stream);
+/* y = act((z - mean) * rstd * gamma + beta [+ res]);  res may be NULL; relu = 0|1 */
+int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, int relu, void* stream);
+size_t hp_bn_backward_workspace_bytes(int C);
+/* g = dy * [y > 0] (stored to g_out if not NULL: gradient of the residual branch);
+ * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL. */
+int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
+                   const float* mean, const float* rstd, const float* gamma, int relu, int train, float* dgamma,
+                   float* dbeta, void* workspace, void* stream);
+/* MaxPool3d(kernel 3, stride 2, padding 1) (posenet3d_50.py:184), channels-last. */
+int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
+int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H, int W,
+                               int C, void* stream);
+/* [B][V][C] -> [B][C][V] (to_channels_first = 1) or back (0). */
+int hp_layout_transpose(const float* in, float* out, int B, long V, int C, int to_channels_first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,165 @@
+"""GPU parity of the pose-regressor building blocks (C ABI: hp_conv3d_*, hp_bn_*, hp_maxpool3d_*)
+against float64 CPU evaluations of the same reference operators (nn.Conv3d / ConvTranspose3d /
+BatchNorm3d / MaxPool3d as used by models/posenet3d_50.py) and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hiddenpose_amd import hip_ops as ops
+from hiddenpose_amd import testing as hpt
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def cl(x):  # (B,C,D,H,W) -> channels-last (B,D,H,W,C)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+CASES = [
+    # name, Cin, Cout, k, stride, pad, transposed, (B, D, H, W)
+    ("k1", 64, 64, 1, 1, 0, False, (2, 4, 6, 8)),
+    ("k1_wide", 256, 96, 1, 1, 0, False, (1, 4, 4, 8)),
+    ("k3", 64, 64, 3, 1, 1, False, (2, 6, 4, 8)),
+    ("k3_s2", 128, 160, 3, 2, 1, False, (1, 8, 4, 6)),
+    ("k1_s2", 64, 256, 1, 2, 0, False, (2, 4, 4, 8)),
+    ("deconv", 64, 32, 4, 2, 1, True, (2, 3, 4, 2)),
+    ("stem", 1, 64, 7, 1, 3, False, (1, 10, 12, 9)),
+    ("head", 256, 24, 1, 1, 0, False, (1, 4, 4, 4)),
+]
+
+
+@pytest.mark.parametrize("name,cin,cout,k,s,p,tr,dims", CASES, ids=[c[0] for c in CASES])
+def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims):
+    import ctypes as C
+
+    from hiddenpose_amd import _lib
+
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    B, D, H, W = dims
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = torch.randn((cin, cout, k, k, k) if tr else (cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3 / s ** 3)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv_transpose3d(xd, wd, stride=s, padding=p) if tr else F.conv3d(xd, wd, stride=s, padding=p)
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy.double()).sum().backward()
+
+    L = _lib.lib()
+    xc = cl(x).cuda()
+    wc = w.cuda()
+    desc = ops._desc(xc, cout, k, s, p, tr)
+    st = ops._stream(xc)
+    wf, _ = ops._pack(desc, wc, True, False)
+    do, ho, wo = ops._out_dims(desc)
+    assert (do, ho, wo) == tuple(ref.shape[2:])
+    y = torch.empty(B, do, ho, wo, cout, device="cuda")
+    stats = torch.empty(2 * cout, dtype=torch.float64, device="cuda")
+    _lib.check(L.hp_conv3d_forward(C.byref(desc), xc.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st), "fwd")
+    assert rel_l2(ncdhw(y), ref) < 2e-6
+    refcl = cl(ref.detach())
+    assert rel_l2(stats[:cout], refcl.reshape(-1, cout).sum(0)) < 1e-5
+    assert rel_l2(stats[cout:], (refcl.reshape(-1, cout) ** 2).sum(0)) < 1e-5
+    dx, dw = ops._conv_grads(desc, xc, wc, cl(gy).cuda(), True)
+    assert rel_l2(ncdhw(dx), xd.grad) < 5e-6
+    assert rel_l2(dw, wd.grad) < 5e-6
+
+
+@pytest.mark.parametrize("train,relu,with_res", [(True, True, True), (True, True, False), (False, True, True), (True, False, False)])
+def test_conv_bn_act_unit(train, relu, with_res):
+    g = torch.Generator().manual_seed(11)
+    B, C1, C2, D = 2, 64, 96, 6
+    conv = torch.nn.Conv3d(C1, C2, 3, padding=1, bias=False)
+    bn = torch.nn.BatchNorm3d(C2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+        bn.weight.copy_(1 + 0.2 * torch.randn(C2, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C2, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(C2, generator=g))
+        bn.running_var.copy_(1 + 0.1 * torch.rand(C2, generator=g))
+    x = torch.randn(B, C1, D, D, D, generator=g)
+    res = torch.randn(B, C2, D, D, D, generator=g) if with_res else None
+    gy = torch.randn(B, C2, D, D, D, generator=g)
+
+    import copy
+
+    convr, bnr = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    bnr.train(train)
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    o = bnr(convr(xr))
+    if with_res:
+        o = o + rr
+    if relu:
+        o = F.relu(o)
+    (o * gy.double()).sum().backward()
+
+    convg, bng = conv.cuda(), bn.cuda()
+    bng.train(train)
+    xg = cl(x).cuda().requires_grad_(True)
+    rg = cl(res).cuda().requires_grad_(True) if with_res else None
+    y = ops.conv_bn_act(xg, convg, bng, relu=relu, residual=rg)
+    (y * cl(gy).cuda()).sum().backward()
+    assert rel_l2(ncdhw(y), o) < 1e-5
+    assert rel_l2(ncdhw(xg.grad), xr.grad) < 1e-4
+    assert rel_l2(convg.weight.grad, convr.weight.grad) < 1e-4
+    assert rel_l2(bng.weight.grad, bnr.weight.grad) < 1e-4
+    assert rel_l2(bng.bias.grad, bnr.bias.grad) < 1e-4
+    if with_res:
+        assert rel_l2(ncdhw(rg.grad), rr.grad) < 1e-6
+    assert rel_l2(bng.running_mean, bnr.running_mean) < 1e-5
+    assert rel_l2(bng.running_var, bnr.running_var) < 1e-5
+    assert int(bng.num_batches_tracked) == int(bnr.num_batches_tracked)
+
+
+def test_maxpool_k3s2():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 8, 6, 8, 4, generator=g)
+    xr = x.double().requires_grad_(True)
+    o = F.max_pool3d(xr, 3, 2, 1)
+    gy = torch.randn(o.shape, generator=g)
+    (o * gy.double()).sum().backward()
+    xg = cl(x).cuda().requires_grad_(True)
+    y = ops._MaxPool3CL.apply(xg)
+    (y * cl(gy).cuda()).sum().backward()
+    assert rel_l2(ncdhw(y), o) == 0.0
+    assert rel_l2(ncdhw(xg.grad), xr.grad) < 1e-7
+
+
+def test_posenet_vs_reference_golden(golden):
+    from hiddenpose_amd.posenet3d_50 import get_pose_net_50
+
+    g = golden("posenet_io.npz")
+    net = get_pose_net_50()
+    hpt.fill_module(net, "pose_net.")
+    net = net.cuda()
+    x = (hpt.synthetic_meas(1, 32, 32, "uniform", seed=104) * 10.0).cuda()
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    assert rel_l2(y, g["eval_y"]) < 1e-4
+    net.train()
+    x2 = (hpt.synthetic_meas(2, 32, 32, "uniform", seed=105) * 10.0).cuda().requires_grad_(True)
+    yt = net(x2)
+    gy = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(yt.shape)).astype(np.float32)).cuda()
+    (yt * gy).sum().backward()
+    assert rel_l2(yt, g["train_y"]) < 1e-3
+    assert rel_l2(x2.grad, g["train_gx"]) < 1e-2
+    sd = net.state_dict()
+    assert rel_l2(sd["bn1.running_mean"], g["train_bn1_running_mean"]) < 1e-4
+    assert rel_l2(sd["bn1.running_var"], g["train_bn1_running_var"]) < 1e-4
+    assert rel_l2(sd["head.features.7.running_var"], g["train_head7_running_var"]) < 1e-3
+    named = dict(net.named_parameters())
+    for k in ["conv1.weight", "bn1.weight", "layer1.0.conv2.weight", "layer1.0.downsample.0.weight", "layer4.2.bn3.bias",
+              "head.features.9.weight"]:
+        if "train_g_" + k in g:
+            assert rel_l2(named[k].grad, g["train_g_" + k]) < 1e-2, k
+        else:
+            idx = g["train_gidx_" + k]
+            gn = named[k].grad.cpu().numpy().reshape(-1)
+            assert rel_l2(gn[idx], g["train_gs_" + k]) < 1e-2, k
+            assert abs(np.sqrt((gn.astype(np.float64) ** 2).sum()) / float(g["train_gl2_" + k]) - 1) < 1e-2, k
