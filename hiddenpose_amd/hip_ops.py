@@ -12,8 +12,9 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-HIP_STAGES = {"lct_forward", "lct_backward", "posenet3d_50"}
-ATEN_STAGES = {"feature_extraction", "normalize_feature", "unet3d", "softmax_integral", "bce_dice"}
+HIP_STAGES = {"lct_forward", "lct_backward", "posenet3d_50", "feature_extraction.conv", "unet3d.conv3"}
+ATEN_STAGES = {"feature_extraction.leaky_add", "normalize_feature", "unet3d.groupnorm_pool_upsample_out", "softmax_integral",
+               "bce_dice"}
 
 
 def _need_cuda(x: torch.Tensor, what: str) -> None:
@@ -23,16 +24,71 @@ def _need_cuda(x: torch.Tensor, what: str) -> None:
         raise HiddenPoseHipError(f"{what}: tensor is on {x.device}; this package has no CPU path")
 
 
+# ---------------------------------------------------------------- thin-channel 3^3 convolutions
+import ctypes as _C
+
+from . import _lib
+
+
+def _stream(t):
+    return _lib.current_stream_handle(t.device)
+
+
+class _DConv3(torch.autograd.Function):
+    """y = conv3d(x, w, bias), 3x3x3, stride 1, same size, zero or replicate padding; planar
+    (B,C,D,H,W).  csrc/dconv_kernels.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, replicate):
+        _need_cuda(x, "dconv3")
+        L = _lib.lib()
+        x = x.contiguous()
+        b, cin, d, h, wd = x.shape
+        cout = w.shape[0]
+        y = torch.empty(b, cout, d, h, wd, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.hp_dconv3_forward(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), y.data_ptr(), b, cin, cout, d, h, wd,
+                                           1 if replicate else 0, _stream(x)), "hp_dconv3_forward")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (replicate, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        replicate, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        b, cin, d, h, wd = x.shape
+        cout = w.shape[0]
+        rp = 1 if replicate else 0
+        st = _stream(x)
+        gx = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                nb = int(L.hp_dconv3_backward_data_workspace_bytes(b, cin, d, h, wd, rp))
+                ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
+                _lib.check(L.hp_dconv3_backward_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), b, cin, cout, d, h, wd, rp,
+                                                     _lib.ptr(ws), st), "hp_dconv3_backward_data")
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+            _lib.check(L.hp_dconv3_backward_weight(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
+                                                   d, h, wd, rp, st), "hp_dconv3_backward_weight")
+        return gx, dw, db, None
+
+
 # ---------------------------------------------------------------- FeatureExtraction (rows A1, A2)
 def conv3d_reppad(x, w, b, stride=1):
-    return F.conv3d(F.pad(x, (1, 1, 1, 1, 1, 1), mode="replicate"), w, b, stride=stride)
+    assert stride == 1, "NlosPose uses FeatureExtraction with stride 1 (models/NlosPose.py:20-24)"
+    return _DConv3.apply(x, w, b, True)
 
 
 def feature_extraction_fused(x, fe):
     _need_cuda(x, "feature_extraction")
     a = conv3d_reppad(x, fe.conv1[1].weight, fe.conv1[1].bias)
     a = fe.conv1[3](fe.conv1[2](a))
-    return a + F.conv3d(x, fe.weights, None, stride=1, padding=1)
+    return a + _DConv3.apply(x, fe.weights, None, False)
 
 
 # ---------------------------------------------------------------- normalize_feature (row C8)
@@ -47,11 +103,14 @@ def normalize_feature(x):
 
 # ---------------------------------------------------------------- UNet3d (row U1)
 def conv3d(x, w, b=None, stride=1, padding=0):
-    return F.conv3d(x, w, b, stride=stride, padding=padding)
+    """1x1x1 convolution (UNet3d `Out`, unet/unet3d.py:65-71): a per-voxel channel mix."""
+    assert w.shape[2:] == (1, 1, 1) and stride == 1 and padding == 0
+    y = torch.einsum("bcdhw,oc->bodhw", x, w.reshape(w.shape[0], w.shape[1]))
+    return y if b is None else y + b.view(1, -1, 1, 1, 1)
 
 
 def conv3_gn_relu(x, w, b, gw, gb, groups, eps):
-    return F.relu(F.group_norm(F.conv3d(x, w, b, padding=1), groups, gw, gb, eps))
+    return F.relu(F.group_norm(_DConv3.apply(x, w, b, False), groups, gw, gb, eps))
 
 
 def max_pool3d_2(x):
@@ -65,15 +124,6 @@ def upsample_trilinear_2x(x):
 # ---------------------------------------------------------------- posenet3d_50 (rows P1-P3)
 # Channels-last (B, D, H, W, C) fp32 tensors between units; every kernel is in libhiddenpose_hip.so
 # (csrc/conv_kernels.hip: exact-fp32 MFMA implicit GEMM; csrc/norm_kernels.hip: BN / pool / layout).
-import ctypes as _C
-
-from . import _lib
-
-
-def _stream(t):
-    return _lib.current_stream_handle(t.device)
-
-
 def _desc(x_cl, cout, k, stride, pad, transposed):
     b, d, h, w, cin = x_cl.shape
     return _lib.ConvDesc(b, d, h, w, cin, cout, k, stride, pad, 1 if transposed else 0)

@@ -133,6 +133,22 @@ int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, 
 /* [B][V][C] -> [B][C][V] (to_channels_first = 1) or back (0). */
 int hp_layout_transpose(const float* in, float* out, int B, long V, int C, int to_channels_first, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Thin-channel 3x3x3 convolutions, planar (B, C, D, H, W) fp32, stride 1, "same" size:
+ * FeatureExtraction / ResConv3D (models/feature_extraction.py:147-158,167,228-256;
+ * replicate_pad = 1 for the ReplicationPad3d(1)+Conv3d pairs, 0 for the zero-padded box
+ * filter) and UNet3d's DoubleConv convolutions (unet/unet3d.py:15-23).
+ * Weights in the torch layout (Cout, Cin, 3, 3, 3).  Cout in {1,4,8,16,32,64}.
+ * ---------------------------------------------------------------------- */
+int hp_dconv3_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int D,
+                      int H, int W, int replicate_pad, void* stream);
+size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad);
+int hp_dconv3_backward_data(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H, int W,
+                            int replicate_pad, void* workspace, void* stream);
+/* dw (Cout,Cin,3,3,3) and dbias (Cout, may be NULL) are zeroed and accumulated by the call. */
+int hp_dconv3_backward_weight(const float* x, const float* gy, float* dw, float* dbias, int B, int cin, int cout, int D,
+                              int H, int W, int replicate_pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
