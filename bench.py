@@ -40,6 +40,45 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
 
 
+def posenet_conv_flops(T: int, N: int, B: int) -> dict:
+    """Algorithmic FLOPs (2 x MAC) per training step of every implicit-GEMM kernel family of
+    posenet3d_50 (models/posenet3d_50.py:156-270), keyed by the profiling name used in
+    csrc/conv_kernels.hip.  Forward, data gradient and weight gradient of a convolution all
+    cost 2 * out_voxels * k^3 * Cin * Cout."""
+    f = {"conv_igemm_stem": 0, "conv_igemm_k1": 0, "conv_igemm_k3": 0, "conv_igemm_deconv": 0, "conv_igemm_dgrad": 0,
+         "conv_stem_dgrad": 0, "conv_wgrad": 0}
+    vox = B * T * N * N
+    stem = 2 * vox * 343 * 64
+    f["conv_igemm_stem"] += stem
+    f["conv_stem_dgrad"] += stem
+    f["conv_wgrad"] += stem
+    v = vox // 8  # after MaxPool3d(3,2,1)
+    inpl = 64
+
+    def add(name, flops):
+        f[name] += flops
+        f["conv_igemm_dgrad"] += flops
+        f["conv_wgrad"] += flops
+
+    for li, (nb, pl) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            vin, vout = v, v // (stride ** 3)
+            add("conv_igemm_k1", 2 * vin * inpl * pl)            # conv1 at the input resolution
+            add("conv_igemm_k3", 2 * vout * 27 * pl * pl)        # conv2 carries the stride
+            add("conv_igemm_k1", 2 * vout * pl * pl * 4)         # conv3
+            if bi == 0:
+                add("conv_igemm_k1", 2 * vout * inpl * pl * 4)   # shortcut type 'B'
+            inpl, v = pl * 4, vout
+    cin = 2048
+    for _ in range(3):
+        v *= 8
+        add("conv_igemm_deconv", 2 * v * 8 * cin * 256)          # k4 s2: 8 taps reach each output voxel
+        cin = 256
+    add("conv_igemm_k1", 2 * v * 256 * 24)
+    return f
+
+
 def algorithmic_work(kernel: str, T: int, N: int, B: int):
     """(bound, unit amount per launch) for each hand-written kernel; derivations in DESIGN.md.
     V = T*N*N voxels, P = ceil(B/2) packed pairs, complex64 = 8 B."""
@@ -188,7 +227,16 @@ def main():
         if prof:
             name, (n, ms) = max(prof.items(), key=lambda kv: kv[1][1])
             work = algorithmic_work(name, T, N, B)
-            if work and n:
+            conv = posenet_conv_flops(T, N, B)
+            if name in conv and n:
+                # one profiling name covers every layer's launch of that kernel family:
+                # achieved = total algorithmic FLOPs of the family / total time of its launches
+                ach = conv[name] * args.steps / (ms / 1e3) / 1e12
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches": n,
+                        "avg_launch_us": round(1e3 * ms / n, 2),
+                        "gflop_per_step": round(conv[name] / 1e9, 1)}
+            elif work and n:
                 bound, amount = work
                 avg_s = ms / n / 1e3
                 if bound == "hbm":
@@ -199,6 +247,9 @@ def main():
                         "frac": round(ach / peak, 4), "traffic": None, "launches": n,
                         "avg_launch_us": round(1e3 * ms / n, 2)}
             line["hip_kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}
+            cf = posenet_conv_flops(T, N, B)
+            line["mfma_tflops_by_kernel"] = {k: round(cf[k] * args.steps / (prof[k][1] / 1e3) / 1e12, 1)
+                                             for k in sorted(cf) if k in prof and prof[k][1] > 0}
         line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)

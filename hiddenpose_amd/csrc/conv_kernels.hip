@@ -396,6 +396,97 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
   }
 }
 
+
+// ---------------------------------------------------------------- stem data gradient
+// dX[j + k - 3] += sum_n dZ[j][n] * w[n][k]   (7^3 taps, 64 channels -> 1 channel)
+// As an implicit GEMM this has N = 1, so it is computed the other way round: per 4x4x8 voxel
+// patch P[j][k] = dZ[j][:] . w[:][k] is a dense 128 x 343 x 64 GEMM on the matrix cores, and the
+// 343 columns are scatter-added (col2im) into a 10x10x14 LDS patch that is flushed to dX
+// with one fp32 atomic per touched voxel.
+constexpr int SP_Z = 4, SP_Y = 4, SP_X = 8, SP_M = SP_Z * SP_Y * SP_X;  // 128 voxels
+constexpr int SR_Z = SP_Z + 6, SR_Y = SP_Y + 6, SR_X = SP_X + 6, SR_N = SR_Z * SR_Y * SR_X;
+constexpr int SLD = 65;
+
+__global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
+                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px) {
+  __shared__ float As[SP_M * SLD];
+  __shared__ float Bs[32 * SLD];
+  __shared__ float patch[SR_N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t = blockIdx.x;
+  const int bx = t % px;
+  t /= px;
+  const int by = t % py;
+  const int bz = t / py;
+  (void)pz;
+  const int b = blockIdx.y;
+  const int z0 = bz * SP_Z, y0 = by * SP_Y, x0 = bx * SP_X;
+  for (int i = tid; i < SR_N; i += CT) patch[i] = 0.f;
+  // A tile: 128 voxels x 64 channels
+  {
+    const int q = tid & 15, r0 = tid >> 4;
+#pragma unroll
+    for (int pss = 0; pss < SP_M / 16; ++pss) {
+      const int r = r0 + 16 * pss;
+      const int rz = r / (SP_Y * SP_X), ry = (r / SP_X) % SP_Y, rx = r % SP_X;
+      const int z = z0 + rz, y = y0 + ry, x = x0 + rx;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (z < D && y < H && x < W) v = *(const float4*)(dZ + ((((long)b * D + z) * H + y) * W + x) * 64 + q * 4);
+      float* d = As + r * SLD + q * 4;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+  }
+  // static scatter geometry of this lane's 16 accumulator rows
+  int cell_row[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int rz = row / (SP_Y * SP_X), ry = (row / SP_X) % SP_Y, rx = row % SP_X;
+    cell_row[r] = (rz * SR_Y + ry) * SR_X + rx;
+  }
+  const float* ap = As + (wave * 32 + (lane & 31)) * SLD + (lane >> 5);
+  const float* bp = Bs + (lane & 31) * SLD + (lane >> 5);
+  for (int chunk = 0; chunk < 11; ++chunk) {
+    __syncthreads();  // previous chunk's fragment reads are finished (and As / patch are ready)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = tid + h * CT;  // 512 float4 = 32 taps x 16 quads
+      const int tr = i >> 4, q = i & 15;
+      const int tap = chunk * 32 + tr;
+      float4 v = make_float4(0, 0, 0, 0);
+      if (tap < 343) v = *(const float4*)(Wt + (long)tap * 64 + q * 4);
+      float* d = Bs + tr * SLD + q * 4;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk], acc, 0, 0, 0);
+    const int tap = chunk * 32 + (lane & 31);
+    if (tap < 343) {
+      const int kd = tap / 49, kh = (tap / 7) % 7, kw = tap % 7;
+      const int toff = (kd * SR_Y + kh) * SR_X + kw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(&patch[cell_row[r] + toff], acc[r]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < SR_N; i += CT) {
+    const int cz = i / (SR_Y * SR_X), cy = (i / SR_X) % SR_Y, cx = i % SR_X;
+    const int z = z0 + cz - 3, y = y0 + cy - 3, x = x0 + cx - 3;
+    if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+      atomicAdd(dX + (((long)b * D + z) * H + y) * W + x, patch[i]);
+  }
+}
+
 // ---------------------------------------------------------------- weight (un)packing
 // torch Conv3d weight (Cout,Cin,k,k,k)  <->  packed [tap][Cout][Cin]   (transposed=0)
 // torch ConvTranspose3d weight (Cin,Cout,k,k,k) <-> packed [tap][Cout][Cin]   (transposed=1)
@@ -605,6 +696,16 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
   int rc = make_plan(*d, p);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (p.stem) {
+    HP_REQUIRE(d->Cout == 64, "stem data gradient: 64 output channels expected (got %d)", d->Cout);
+    HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi, st));
+    const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
+    HP_PROF("conv_stem_dgrad", st);
+    hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, dy, w_dgrad, dx,
+                       d->Di, d->Hi, d->Wi, pz, py, px);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+  }
   if (p.dgrad_zero_fill)
     HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin, st));
   {
