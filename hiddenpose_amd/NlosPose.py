@@ -41,5 +41,5 @@ class NlosPose(nn.Module):
         feature = self.feature_propagation(meas, [self.time_begin] * b, [self.time_end] * b)
         feature = ops.normalize_feature(feature)
         refine_feature = self.autoencoder(feature)
-        output = self.pose_net(feature + refine_feature)
+        output = self.pose_net(ops.add(feature, refine_feature))
         return output, refine_feature

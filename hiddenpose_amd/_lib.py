@@ -54,6 +54,24 @@ SIGNATURES = {
     "hp_dconv3_backward_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "hp_dconv3_backward_data": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_dconv3_backward_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_groupnorm_workspace_bytes": (_sz, [_i, _i]),
+    "hp_groupnorm_relu_forward": (_i, [_fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, C.c_float, _fp, _fp, _vp, _vp]),
+    "hp_groupnorm_relu_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "hp_maxpool3d_k2_forward": (_i, [_fp, _fp, C.c_long, _i, _i, _i, _vp]),
+    "hp_maxpool3d_k2_backward": (_i, [_fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
+    "hp_upsample_trilinear2x_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_upsample_trilinear2x_backward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_channel_slice_copy": (_i, [_fp, _fp, _i, _i, C.c_long, _i, _i, _i, _vp]),
+    "hp_conv1x1_forward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
+    "hp_conv1x1_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
+    "hp_leaky_add_forward": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _vp]),
+    "hp_leaky_backward": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _vp]),
+    "hp_normalize_feature_forward": (_i, [_fp, _fp, _i, C.c_long, C.c_float, _vp, _vp]),
+    "hp_normalize_feature_backward": (_i, [_fp, _fp, _fp, _i, C.c_long, C.c_float, _vp, _vp, _vp]),
+    "hp_softargmax_forward": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "hp_softargmax_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "hp_bce_dice_forward": (_i, [_fp, _fp, C.c_long, C.c_float, _vp, _fp, _vp]),
+    "hp_bce_dice_backward": (_i, [_fp, _fp, _vp, _fp, _fp, C.c_long, C.c_float, _vp]),
 }
 
 

@@ -1,0 +1,379 @@
+// Small memory-bound stages around the convolutions:
+//  * FeatureExtraction's leaky-ReLU / residual elementwise steps (feature_extraction.py:228-256)
+//  * normalize_feature (feature_propagation.py:273-286): per-volume min/max rescale to [0,10]
+//  * soft-argmax decode (utils/criterion.py:96-153) with its backward
+//  * BCE-with-logits + batch-global Dice loss (utils/criterion.py:348-385)
+// Reductions: wavefront shuffles -> LDS -> one atomic (or one store) per block.
+#include <algorithm>
+#include <cfloat>
+
+#include "hp_internal.h"
+
+namespace hp {
+
+constexpr int MT = 256;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wmin(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// y = leaky(a [+ b], slope)
+__global__ __launch_bounds__(MT) void k_leaky_add(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                  float4* __restrict__ y, long n4, float slope) {
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n4; i += (long)gridDim.x * MT) {
+    float4 v = a[i];
+    if (b) {
+      const float4 w = b[i];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    v.x = v.x > 0.f ? v.x : v.x * slope;
+    v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope;
+    v.w = v.w > 0.f ? v.w : v.w * slope;
+    y[i] = v;
+  }
+}
+// g = dy * (y > 0 ? 1 : slope)   (leaky ReLU keeps the sign, so the output tells the branch)
+__global__ __launch_bounds__(MT) void k_leaky_bwd(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                  float4* __restrict__ g, long n4, float slope) {
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n4; i += (long)gridDim.x * MT) {
+    const float4 d = dy[i], v = y[i];
+    g[i] = make_float4(v.x > 0.f ? d.x : d.x * slope, v.y > 0.f ? d.y : d.y * slope, v.z > 0.f ? d.z : d.z * slope,
+                       v.w > 0.f ? d.w : d.w * slope);
+  }
+}
+
+// ---- normalize_feature.  Pass 1: per-volume min / max with first-occurrence indices.
+// Orderable encoding: key = (float bits made monotone) << 32 | index  -> one 64-bit atomic.
+__device__ __forceinline__ unsigned int mono(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unmono(unsigned int m) {
+  return __uint_as_float((m & 0x80000000u) ? (m & 0x7fffffffu) : ~m);
+}
+
+__global__ __launch_bounds__(MT) void k_minmax(const float* __restrict__ x, unsigned long long* __restrict__ keys, long V) {
+  // keys[2*vol] = min key (value, index) ; keys[2*vol+1] = max key (value, ~index so the FIRST index wins)
+  const long vol = blockIdx.y;
+  const float* p = x + vol * V;
+  unsigned long long kmin = ~0ull, kmax = 0ull;
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < V; i += (long)gridDim.x * MT) {
+    const unsigned int m = mono(p[i]);
+    const unsigned long long a = ((unsigned long long)m << 32) | (unsigned int)i;
+    const unsigned long long b = ((unsigned long long)m << 32) | (unsigned int)(~(unsigned int)i);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(keys + 2 * vol, kmin);
+    atomicMax(keys + 2 * vol + 1, kmax);
+  }
+}
+
+__global__ __launch_bounds__(MT) void k_normalize_apply(const float* __restrict__ x, float* __restrict__ y,
+                                                        const unsigned long long* __restrict__ keys, long V, float gain) {
+  const long vol = blockIdx.y;
+  const float mn = unmono((unsigned int)(keys[2 * vol] >> 32)), mx = unmono((unsigned int)(keys[2 * vol + 1] >> 32));
+  const float inv = 1.0f / ((mx - mn) + 1e-15f);
+  const float4* p = (const float4*)(x + vol * V);
+  float4* o = (float4*)(y + vol * V);
+  const long n4 = V / 4;
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n4; i += (long)gridDim.x * MT) {
+    float4 v = p[i];
+    v.x = (v.x - mn) * inv * gain;
+    v.y = (v.y - mn) * inv * gain;
+    v.z = (v.z - mn) * inv * gain;
+    v.w = (v.w - mn) * inv * gain;
+    o[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < V; i += MT) y[vol * V + i] = (x[vol * V + i] - mn) * inv * gain;
+}
+
+// backward: y = gain * (x - mn) / R, R = (mx - mn) + eps.
+// dx_i = gain dy_i / R ; at argmax: -= gain S2 / R^2 ; at argmin: += gain S2 / R^2 - gain S1 / R
+// with S1 = sum dy, S2 = sum dy (x - mn)
+__global__ __launch_bounds__(MT) void k_normalize_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const unsigned long long* __restrict__ keys,
+                                                             double* __restrict__ acc, long V) {
+  __shared__ float sh[2 * MT / 64];
+  const long vol = blockIdx.y;
+  const float mn = unmono((unsigned int)(keys[2 * vol] >> 32));
+  float s1 = 0.f, s2 = 0.f;
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < V; i += (long)gridDim.x * MT) {
+    const float d = dy[vol * V + i];
+    s1 += d;
+    s2 += d * (x[vol * V + i] - mn);
+  }
+  s1 = wsum(s1);
+  s2 = wsum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    sh[(threadIdx.x >> 6) * 2] = s1;
+    sh[(threadIdx.x >> 6) * 2 + 1] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < MT / 64; ++w) {
+      a += sh[2 * w];
+      b += sh[2 * w + 1];
+    }
+    atomicAdd(acc + 2 * vol, (double)a);
+    atomicAdd(acc + 2 * vol + 1, (double)b);
+  }
+}
+
+__global__ __launch_bounds__(MT) void k_normalize_bwd_apply(const float* __restrict__ dy, float* __restrict__ dx,
+                                                            const unsigned long long* __restrict__ keys,
+                                                            const double* __restrict__ acc, long V, float gain) {
+  const long vol = blockIdx.y;
+  const unsigned long long kmin = keys[2 * vol], kmax = keys[2 * vol + 1];
+  const float mn = unmono((unsigned int)(kmin >> 32)), mx = unmono((unsigned int)(kmax >> 32));
+  const unsigned int imin = (unsigned int)kmin, imax = ~(unsigned int)kmax;
+  const double R = (double)(mx - mn) + 1e-15;
+  const float inv = (float)((double)gain / R);
+  const float t2 = (float)((double)gain * acc[2 * vol + 1] / (R * R)), t1 = (float)((double)gain * acc[2 * vol] / R);
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < V; i += (long)gridDim.x * MT) {
+    float v = dy[vol * V + i] * inv;
+    if ((unsigned int)i == imax) v -= t2;
+    if ((unsigned int)i == imin) v += t2 - t1;
+    dx[vol * V + i] = v;
+  }
+}
+
+// ---- soft-argmax: one workgroup per (b, joint) heat-map of D*H*W logits.
+// out[bj*3 + {0,1,2}] = E[w], E[h], E[d];  stat[bj*2 + {0,1}] = max logit, sum exp(l - max)
+__global__ __launch_bounds__(MT) void k_softargmax_fwd(const float* __restrict__ heat, float* __restrict__ out,
+                                                       float* __restrict__ stat, int D, int H, int W) {
+  __shared__ float sh[4 * MT / 64];
+  const long bj = blockIdx.x;
+  const long V = (long)D * H * W;
+  const float* p = heat + bj * V;
+  float m = -FLT_MAX;
+  for (long i = threadIdx.x; i < V; i += MT) m = fmaxf(m, p[i]);
+  m = wmax(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = sh[0];
+  for (int w = 1; w < MT / 64; ++w) m = fmaxf(m, sh[w]);
+  __syncthreads();
+  float s = 0.f, ex = 0.f, ey = 0.f, ez = 0.f;
+  for (long i = threadIdx.x; i < V; i += MT) {
+    const float e = __expf(p[i] - m);
+    const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((long)W * H));
+    s += e;
+    ex += e * (float)x;
+    ey += e * (float)y;
+    ez += e * (float)z;
+  }
+  s = wsum(s);
+  ex = wsum(ex);
+  ey = wsum(ey);
+  ez = wsum(ez);
+  if ((threadIdx.x & 63) == 0) {
+    float* q = sh + (threadIdx.x >> 6) * 4;
+    q[0] = s; q[1] = ex; q[2] = ey; q[3] = ez;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0, b = 0, c = 0, d = 0;
+    for (int w = 0; w < MT / 64; ++w) {
+      a += sh[4 * w]; b += sh[4 * w + 1]; c += sh[4 * w + 2]; d += sh[4 * w + 3];
+    }
+    out[bj * 3 + 0] = b / a;
+    out[bj * 3 + 1] = c / a;
+    out[bj * 3 + 2] = d / a;
+    stat[bj * 2] = m;
+    stat[bj * 2 + 1] = a;
+  }
+}
+
+// d logit_i = p_i * sum_a g_a (coord_a(i) - E_a)
+__global__ __launch_bounds__(MT) void k_softargmax_bwd(const float* __restrict__ heat, const float* __restrict__ out,
+                                                       const float* __restrict__ stat, const float* __restrict__ gout,
+                                                       float* __restrict__ dheat, int D, int H, int W, int chunks) {
+  const long bj = blockIdx.x / chunks;
+  const int chunk = blockIdx.x % chunks;
+  const long V = (long)D * H * W;
+  const float m = stat[bj * 2], inv = 1.0f / stat[bj * 2 + 1];
+  const float gx = gout[bj * 3], gy = gout[bj * 3 + 1], gz = gout[bj * 3 + 2];
+  const float ex = out[bj * 3], ey = out[bj * 3 + 1], ez = out[bj * 3 + 2];
+  for (long i = (long)chunk * MT + threadIdx.x; i < V; i += (long)chunks * MT) {
+    const float pr = __expf(heat[bj * V + i] - m) * inv;
+    const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((long)W * H));
+    dheat[bj * V + i] = pr * (gx * ((float)x - ex) + gy * ((float)y - ey) + gz * ((float)z - ez));
+  }
+}
+
+// ---- BCE-with-logits + Dice.  acc[0..3] = sum bce_i, sum sig*t, sum sig, sum t  (fp64)
+__global__ __launch_bounds__(MT) void k_bce_dice_reduce(const float* __restrict__ logit, const float* __restrict__ target,
+                                                        double* __restrict__ acc, long n) {
+  __shared__ float sh[4 * MT / 64];
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n; i += (long)gridDim.x * MT) {
+    const float x = logit[i], t = target[i];
+    // max(x,0) - x t + log(1 + exp(-|x|))
+    a += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+    const float s = 1.0f / (1.0f + __expf(-x));
+    b += s * t;
+    c += s;
+    d += t;
+  }
+  a = wsum(a); b = wsum(b); c = wsum(c); d = wsum(d);
+  if ((threadIdx.x & 63) == 0) {
+    float* q = sh + (threadIdx.x >> 6) * 4;
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float s = 0.f;
+    for (int w = 0; w < MT / 64; ++w) s += sh[4 * w + threadIdx.x];
+    atomicAdd(acc + threadIdx.x, (double)s);
+  }
+}
+
+__global__ void k_bce_dice_finish(const double* __restrict__ acc, long n, float eps, float* __restrict__ loss) {
+  const double bce = acc[0] / (double)n;
+  const double dice = (2.0 * acc[1] + (double)eps) / (acc[2] + acc[3]);
+  loss[0] = (float)(bce + 1.0 - dice);
+}
+
+// d loss / d x_i = gl * [ (sig - t)/n  -  dDice/dsig_i * sig (1 - sig) ],
+// dDice/dsig_i = (2 t_i U - (2 I + eps)) / U^2,  U = sum sig + sum t
+__global__ __launch_bounds__(MT) void k_bce_dice_bwd(const float* __restrict__ logit, const float* __restrict__ target,
+                                                     const double* __restrict__ acc, const float* __restrict__ gl,
+                                                     float* __restrict__ dlogit, long n, float eps) {
+  const double U = acc[2] + acc[3];
+  const float invn = (float)(1.0 / (double)n);
+  const float c1 = (float)(2.0 / U), c0 = (float)((2.0 * acc[1] + (double)eps) / (U * U));
+  const float g = gl[0];
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n; i += (long)gridDim.x * MT) {
+    const float x = logit[i], t = target[i];
+    const float s = 1.0f / (1.0f + __expf(-x));
+    dlogit[i] = g * ((s - t) * invn - (t * c1 - c0) * s * (1.0f - s));
+  }
+}
+
+static unsigned mgrid(long n) { return (unsigned)std::max<long>(1, std::min<long>((n + MT - 1) / MT, 256 * 8)); }
+
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" int hp_leaky_add_forward(const float* a, const float* b, float* y, long n, float slope, void* stream) {
+  HP_REQUIRE(a && y && n % 4 == 0, "hp_leaky_add_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("leaky_add", st);
+  hipLaunchKernelGGL(k_leaky_add, dim3(mgrid(n / 4)), dim3(MT), 0, st, (const float4*)a, (const float4*)b, (float4*)y, n / 4, slope);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_leaky_backward(const float* dy, const float* y, float* g, long n, float slope, void* stream) {
+  HP_REQUIRE(dy && y && g && n % 4 == 0, "hp_leaky_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("leaky_bwd", st);
+  hipLaunchKernelGGL(k_leaky_bwd, dim3(mgrid(n / 4)), dim3(MT), 0, st, (const float4*)dy, (const float4*)y, (float4*)g, n / 4, slope);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// keys: 2*nvol uint64 saved for backward
+extern "C" int hp_normalize_feature_forward(const float* x, float* y, int nvol, long V, float gain, void* keys, void* stream) {
+  HP_REQUIRE(x && y && keys && nvol > 0 && V > 0 && V < (1l << 32), "hp_normalize_feature_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  // min slots start at all-ones, max slots at zero
+  HP_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * 2 * nvol, st));
+  HP_CHECK_HIP(hipMemset2DAsync(keys, 16, 0xff, 8, nvol, st));
+  const unsigned chunks = (unsigned)std::max<long>(1, std::min<long>(2048 / nvol, (V + MT - 1) / MT));
+  {
+    HP_PROF("normalize_minmax", st);
+    hipLaunchKernelGGL(k_minmax, dim3(chunks, nvol), dim3(MT), 0, st, x, (unsigned long long*)keys, V);
+  }
+  {
+    HP_PROF("normalize_apply", st);
+    hipLaunchKernelGGL(k_normalize_apply, dim3(chunks, nvol), dim3(MT), 0, st, x, y, (const unsigned long long*)keys, V, gain);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// workspace: 2*nvol doubles
+extern "C" int hp_normalize_feature_backward(const float* dy, const float* x, float* dx, int nvol, long V, float gain,
+                                             const void* keys, void* workspace, void* stream) {
+  HP_REQUIRE(dy && x && dx && keys && workspace && nvol > 0, "hp_normalize_feature_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_CHECK_HIP(hipMemsetAsync(workspace, 0, sizeof(double) * 2 * nvol, st));
+  const unsigned chunks = (unsigned)std::max<long>(1, std::min<long>(2048 / nvol, (V + MT - 1) / MT));
+  HP_PROF("normalize_bwd", st);
+  hipLaunchKernelGGL(k_normalize_bwd_reduce, dim3(chunks, nvol), dim3(MT), 0, st, dy, x, (const unsigned long long*)keys,
+                     (double*)workspace, V);
+  hipLaunchKernelGGL(k_normalize_bwd_apply, dim3(chunks, nvol), dim3(MT), 0, st, dy, dx, (const unsigned long long*)keys,
+                     (const double*)workspace, V, gain);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_softargmax_forward(const float* heat, float* joints, float* stat, int BJ, int D, int H, int W, void* stream) {
+  HP_REQUIRE(heat && joints && stat && BJ > 0, "hp_softargmax_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("softargmax_fwd", st);
+  hipLaunchKernelGGL(k_softargmax_fwd, dim3(BJ), dim3(MT), 0, st, heat, joints, stat, D, H, W);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_softargmax_backward(const float* heat, const float* joints, const float* stat, const float* gjoints,
+                                      float* dheat, int BJ, int D, int H, int W, void* stream) {
+  HP_REQUIRE(heat && joints && stat && gjoints && dheat && BJ > 0, "hp_softargmax_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long V = (long)D * H * W;
+  const int chunks = (int)std::max<long>(1, std::min<long>(32, (V + MT * 8 - 1) / (MT * 8)));
+  HP_PROF("softargmax_bwd", st);
+  hipLaunchKernelGGL(k_softargmax_bwd, dim3((unsigned)(BJ * chunks)), dim3(MT), 0, st, heat, joints, stat, gjoints, dheat, D, H,
+                     W, chunks);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// acc: 4 doubles kept for backward; loss: 1 float
+extern "C" int hp_bce_dice_forward(const float* logit, const float* target, long n, float eps, double* acc, float* loss,
+                                   void* stream) {
+  HP_REQUIRE(logit && target && acc && loss && n > 0, "hp_bce_dice_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, st));
+  HP_PROF("bce_dice_fwd", st);
+  hipLaunchKernelGGL(k_bce_dice_reduce, dim3(mgrid(n)), dim3(MT), 0, st, logit, target, acc, n);
+  hipLaunchKernelGGL(k_bce_dice_finish, dim3(1), dim3(1), 0, st, acc, n, eps, loss);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_bce_dice_backward(const float* logit, const float* target, const double* acc, const float* gloss,
+                                    float* dlogit, long n, float eps, void* stream) {
+  HP_REQUIRE(logit && target && acc && gloss && dlogit && n > 0, "hp_bce_dice_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("bce_dice_bwd", st);
+  hipLaunchKernelGGL(k_bce_dice_bwd, dim3(mgrid(n)), dim3(MT), 0, st, logit, target, acc, gloss, dlogit, n, eps);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}

@@ -1,0 +1,579 @@
+// Memory-bound stages of UNet3d (unet/unet3d.py) on planar fp32 (B, C, D, H, W):
+// GroupNorm(4)+ReLU forward/backward, MaxPool3d(2), trilinear x2 upsampling with
+// align_corners=True written straight into the concatenation buffer, and the 1x1x1 output
+// convolution.  One pass per tensor wherever the statistics allow it, 16-byte accesses.
+#include <algorithm>
+
+#include "hp_internal.h"
+
+namespace hp {
+
+constexpr int UT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum of two values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* sh) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh[wave * 2] = a;
+    sh[wave * 2 + 1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = 0.f;
+    b = 0.f;
+    for (int w = 0; w < UT / 64; ++w) {
+      a += sh[w * 2];
+      b += sh[w * 2 + 1];
+    }
+  }
+  __syncthreads();
+}
+
+// ---- GroupNorm forward: per (b, channel) sum / sum of squares (fp64 atomics), then apply.
+// grid (chunks, B*C); acc[(b*C + c)*2 + {0,1}]
+__global__ __launch_bounds__(UT) void k_plane_stats(const float* __restrict__ z, double* __restrict__ acc, long V) {
+  __shared__ float sh[2 * UT / 64];
+  const long plane = blockIdx.y;
+  const float4* p = (const float4*)(z + plane * V);
+  const long n4 = V / 4;
+  float s = 0.f, q = 0.f;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
+    const float4 v = p[i];
+    s += v.x + v.y + v.z + v.w;
+    q += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < V; i += UT) {
+      const float v = z[plane * V + i];
+      s += v;
+      q += v * v;
+    }
+  block_sum2(s, q, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + plane * 2, (double)s);
+    atomicAdd(acc + plane * 2 + 1, (double)q);
+  }
+}
+
+// per (b, group): mean / rstd from the per-channel sums; per (b, c): scale/shift of the affine map
+__global__ void k_gn_finalize(const double* __restrict__ acc, int B, int C, int G, long V, float eps,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
+                              float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C, cpg = C / G, g = c / cpg;
+  double s = 0, q = 0;
+  for (int k = 0; k < cpg; ++k) {
+    s += acc[((long)b * C + g * cpg + k) * 2];
+    q += acc[((long)b * C + g * cpg + k) * 2 + 1];
+  }
+  const double n = (double)cpg * (double)V;
+  const double m = s / n;
+  double var = q / n - m * m;
+  if (var < 0) var = 0;
+  const double r = 1.0 / sqrt(var + (double)eps);
+  if (c % cpg == 0) {
+    mean[b * G + g] = (float)m;
+    rstd[b * G + g] = (float)r;
+  }
+  scale[i] = (float)(r * gamma[c]);
+  shift[i] = (float)(beta[c] - m * r * gamma[c]);
+}
+
+// y = relu(z * scale[plane] + shift[plane]);  grid (chunks, B*C)
+__global__ __launch_bounds__(UT) void k_affine_relu(const float* __restrict__ z, float* __restrict__ y,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    long V) {
+  const long plane = blockIdx.y;
+  const float a = scale[plane], c = shift[plane];
+  const float4* p = (const float4*)(z + plane * V);
+  float4* o = (float4*)(y + plane * V);
+  const long n4 = V / 4;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
+    float4 v = p[i];
+    v.x = fmaxf(fmaf(v.x, a, c), 0.f);
+    v.y = fmaxf(fmaf(v.y, a, c), 0.f);
+    v.z = fmaxf(fmaf(v.z, a, c), 0.f);
+    v.w = fmaxf(fmaf(v.w, a, c), 0.f);
+    o[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < V; i += UT) y[plane * V + i] = fmaxf(fmaf(z[plane * V + i], a, c), 0.f);
+}
+
+// ---- GroupNorm backward.  g = dy * [y > 0];  per plane: S1 = sum g, S2 = sum g * z
+__global__ __launch_bounds__(UT) void k_gn_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ z, double* __restrict__ acc, long V) {
+  __shared__ float sh[2 * UT / 64];
+  const long plane = blockIdx.y;
+  const float4* pd = (const float4*)(dy + plane * V);
+  const float4* py = (const float4*)(y + plane * V);
+  const float4* pz = (const float4*)(z + plane * V);
+  const long n4 = V / 4;
+  float s = 0.f, q = 0.f;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
+    const float4 d = pd[i], yy = py[i], zz = pz[i];
+    const float g0 = yy.x > 0.f ? d.x : 0.f, g1 = yy.y > 0.f ? d.y : 0.f, g2 = yy.z > 0.f ? d.z : 0.f,
+                g3 = yy.w > 0.f ? d.w : 0.f;
+    s += g0 + g1 + g2 + g3;
+    q += g0 * zz.x + g1 * zz.y + g2 * zz.z + g3 * zz.w;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < V; i += UT) {
+      const float g = y[plane * V + i] > 0.f ? dy[plane * V + i] : 0.f;
+      s += g;
+      q += g * z[plane * V + i];
+    }
+  block_sum2(s, q, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + plane * 2, (double)s);
+    atomicAdd(acc + plane * 2 + 1, (double)q);
+  }
+}
+
+// zhat = (z - m) r.  dgamma_c = sum_b (S2 - m S1) r ; dbeta_c = sum_b S1
+// dz = r gamma_c g - r (A + zhat Bq)/n,  A = sum_{c in grp} gamma_c S1_c,  Bq = sum gamma_c (S2_c - m S1_c) r
+//    = ca * g + cb * z + cc   per plane
+__global__ void k_gn_bwd_coef(const double* __restrict__ acc, int B, int C, int G, long V, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ gamma, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
+                              float* __restrict__ cc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpg = C / G;
+  if (i < C) {  // parameter gradients: reduce over the batch
+    double dg = 0, dbt = 0;
+    const int g = i / cpg;
+    for (int b = 0; b < B; ++b) {
+      const double m = mean[b * G + g], r = rstd[b * G + g];
+      const double s1 = acc[((long)b * C + i) * 2], s2 = acc[((long)b * C + i) * 2 + 1];
+      dg += (s2 - m * s1) * r;
+      dbt += s1;
+    }
+    dgamma[i] = (float)dg;
+    dbeta[i] = (float)dbt;
+  }
+  if (i < B * C) {
+    const int b = i / C, c = i % C, g = c / cpg;
+    const double m = mean[b * G + g], r = rstd[b * G + g];
+    double A = 0, Bq = 0;
+    for (int k = 0; k < cpg; ++k) {
+      const int cj = g * cpg + k;
+      const double s1 = acc[((long)b * C + cj) * 2], s2 = acc[((long)b * C + cj) * 2 + 1];
+      A += gamma[cj] * s1;
+      Bq += gamma[cj] * (s2 - m * s1) * r;
+    }
+    const double n = (double)cpg * (double)V;
+    // dz = r*gamma*g - r/n * (A + (z - m) r Bq)
+    ca[i] = (float)(r * gamma[c]);
+    cb[i] = (float)(-r * r * Bq / n);
+    cc[i] = (float)(-r * A / n + r * r * Bq * m / n);
+  }
+}
+
+__global__ __launch_bounds__(UT) void k_gn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
+                                                     const float* __restrict__ z, float* __restrict__ dz,
+                                                     const float* __restrict__ ca, const float* __restrict__ cb,
+                                                     const float* __restrict__ cc, long V) {
+  const long plane = blockIdx.y;
+  const float a = ca[plane], b = cb[plane], c = cc[plane];
+  const float4* pd = (const float4*)(dy + plane * V);
+  const float4* py = (const float4*)(y + plane * V);
+  const float4* pz = (const float4*)(z + plane * V);
+  float4* po = (float4*)(dz + plane * V);
+  const long n4 = V / 4;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
+    const float4 d = pd[i], yy = py[i], zz = pz[i];
+    float4 o;
+    o.x = fmaf(a, yy.x > 0.f ? d.x : 0.f, fmaf(b, zz.x, c));
+    o.y = fmaf(a, yy.y > 0.f ? d.y : 0.f, fmaf(b, zz.y, c));
+    o.z = fmaf(a, yy.z > 0.f ? d.z : 0.f, fmaf(b, zz.z, c));
+    o.w = fmaf(a, yy.w > 0.f ? d.w : 0.f, fmaf(b, zz.w, c));
+    po[i] = o;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < V; i += UT) {
+      const long j = plane * V + i;
+      dz[j] = fmaf(a, y[j] > 0.f ? dy[j] : 0.f, fmaf(b, z[j], c));
+    }
+}
+
+// ---- MaxPool3d(2, 2): one thread per pooled voxel
+__global__ __launch_bounds__(UT) void k_maxpool2_fwd(const float* __restrict__ x, float* __restrict__ y, long planes, int D,
+                                                     int H, int W) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long total = planes * Do * Ho * Wo;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    const int ow = (int)(i % Wo);
+    long t = i / Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do);
+    const long pl = t / Do;
+    const float* p = x + ((pl * D + 2 * od) * H + 2 * oh) * W + 2 * ow;
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float2 v = *(const float2*)(p + ((long)a * H + b) * W);
+        m = fmaxf(m, fmaxf(v.x, v.y));
+      }
+    y[i] = m;
+  }
+}
+
+// gradient goes to the FIRST maximum of each window (torch semantics)
+__global__ __launch_bounds__(UT) void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     float* __restrict__ dx, long planes, int D, int H, int W) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long total = planes * Do * Ho * Wo;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    const int ow = (int)(i % Wo);
+    long t = i / Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do);
+    const long pl = t / Do;
+    const long base = ((pl * D + 2 * od) * H + 2 * oh) * W + 2 * ow;
+    float v[8];
+    float m = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = x[base + ((long)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1)];
+      if (v[k] > m) {
+        m = v[k];
+        arg = k;
+      }
+    }
+    const float g = dy[i];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int k0 = a * 4 + b * 2;
+        *(float2*)(dx + base + ((long)a * H + b) * W) = make_float2(arg == k0 ? g : 0.f, arg == k0 + 1 ? g : 0.f);
+      }
+  }
+}
+
+// ---- trilinear x2, align_corners=True.  src = o * (n-1)/(2n-1).
+// Forward writes into channel slice [c_off, c_off + C) of a (B, Ctot, 2D, 2H, 2W) buffer.
+__device__ __forceinline__ void lerp_src(int o, int n, int& i0, int& i1, float& w1) {
+  const float s = n > 1 ? (float)o * (float)(n - 1) / (float)(2 * n - 1) : 0.f;
+  i0 = (int)s;
+  if (i0 > n - 1) i0 = n - 1;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(UT) void k_upsample2_fwd(const float* __restrict__ x, float* __restrict__ y, int B, int C, int D,
+                                                      int H, int W, int Ctot, int c_off) {
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * C * Do * Ho * Wo;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    const int ow = (int)(i % Wo);
+    long t = i / Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do);
+    t /= Do;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    int d0, d1, h0, h1, w0, w1;
+    float fd, fh, fw;
+    lerp_src(od, D, d0, d1, fd);
+    lerp_src(oh, H, h0, h1, fh);
+    lerp_src(ow, W, w0, w1, fw);
+    const float* p = x + ((long)b * C + c) * D * H * W;
+    auto at = [&](int a, int bb, int cc) { return p[((long)a * H + bb) * W + cc]; };
+    const float v00 = at(d0, h0, w0) * (1.f - fw) + at(d0, h0, w1) * fw;
+    const float v01 = at(d0, h1, w0) * (1.f - fw) + at(d0, h1, w1) * fw;
+    const float v10 = at(d1, h0, w0) * (1.f - fw) + at(d1, h0, w1) * fw;
+    const float v11 = at(d1, h1, w0) * (1.f - fw) + at(d1, h1, w1) * fw;
+    const float v0 = v00 * (1.f - fh) + v01 * fh, v1 = v10 * (1.f - fh) + v11 * fh;
+    y[(((long)b * Ctot + c_off + c) * Do + od) * Ho * Wo + (long)oh * Wo + ow] = v0 * (1.f - fd) + v1 * fd;
+  }
+}
+
+// adjoint in gather form: every input voxel sums the (<= 4 per axis) outputs that read it
+__device__ __forceinline__ int adj_range(int i, int n, int& lo) {
+  // outputs o with i0(o) == i or i1(o) == i lie in [ceil((i-1)/r), floor((i+1)/r)], r = (n-1)/(2n-1)
+  if (n == 1) {
+    lo = 0;
+    return 2;
+  }
+  const float inv = (float)(2 * n - 1) / (float)(n - 1);
+  int a = (int)floorf((float)(i - 1) * inv) - 1, b = (int)ceilf((float)(i + 1) * inv) + 1;
+  if (a < 0) a = 0;
+  if (b > 2 * n - 1) b = 2 * n - 1;
+  lo = a;
+  return b - a + 1;
+}
+
+__global__ __launch_bounds__(UT) void k_upsample2_bwd(const float* __restrict__ dy, float* __restrict__ dx, int B, int C,
+                                                      int D, int H, int W, int Ctot, int c_off) {
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const long total = (long)B * C * D * H * W;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    const int w = (int)(i % W);
+    long t = i / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int d = (int)(t % D);
+    t /= D;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    int lod, loh, low;
+    const int nd = adj_range(d, D, lod), nh = adj_range(h, H, loh), nw = adj_range(w, W, low);
+    const float* p = dy + ((long)b * Ctot + c_off + c) * Do * Ho * Wo;
+    float acc = 0.f;
+    for (int a = 0; a < nd; ++a) {
+      int i0, i1;
+      float f;
+      lerp_src(lod + a, D, i0, i1, f);
+      const float wd = (i0 == d ? 1.f - f : 0.f) + (i1 == d ? f : 0.f);
+      if (wd == 0.f) continue;
+      for (int bb = 0; bb < nh; ++bb) {
+        lerp_src(loh + bb, H, i0, i1, f);
+        const float wh = (i0 == h ? 1.f - f : 0.f) + (i1 == h ? f : 0.f);
+        if (wh == 0.f) continue;
+        for (int cc = 0; cc < nw; ++cc) {
+          lerp_src(low + cc, W, i0, i1, f);
+          const float ww = (i0 == w ? 1.f - f : 0.f) + (i1 == w ? f : 0.f);
+          if (ww == 0.f) continue;
+          acc += wd * wh * ww * p[((long)(lod + a) * Ho + loh + bb) * Wo + low + cc];
+        }
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// copy (B, C, V) into channel slice [c_off, c_off+C) of (B, Ctot, V), or back (gather = 1)
+__global__ __launch_bounds__(UT) void k_channel_slice_copy(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                           int C, long V, int Ctot, int c_off, int gather) {
+  const long n4 = (long)B * C * V / 4, v4 = V / 4;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
+    const long pl = i / v4, r = i - pl * v4;
+    const int b = (int)(pl / C), c = (int)(pl % C);
+    const long big = (((long)b * Ctot + c_off + c) * v4 + r);
+    if (gather)
+      ((float4*)dst)[i] = ((const float4*)src)[big];
+    else
+      ((float4*)dst)[big] = ((const float4*)src)[i];
+  }
+}
+
+// ---- 1x1x1 convolution with few channels (UNet `Out`: 4 -> 1)
+__global__ __launch_bounds__(UT) void k_conv1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ y, int B, int cin,
+                                                  int cout, long V) {
+  const long total = (long)B * V;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    const long b = i / V, v = i - b * V;
+    for (int co = 0; co < cout; ++co) {
+      float s = bias ? bias[co] : 0.f;
+      for (int ci = 0; ci < cin; ++ci) s = fmaf(x[(b * cin + ci) * V + v], w[co * cin + ci], s);
+      y[(b * cout + co) * V + v] = s;
+    }
+  }
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(UT) void k_conv1_bwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ dy, float* __restrict__ dx,
+                                                  float* __restrict__ dw, float* __restrict__ db, int B, long V) {
+  // per-thread partial sums, block reduction, one atomic per block and entry
+  __shared__ float sh[2 * UT / 64];
+  const long total = (long)B * V;
+  float pw[CIN * COUT], pb[COUT], wr[CIN * COUT];
+#pragma unroll
+  for (int k = 0; k < CIN * COUT; ++k) {
+    pw[k] = 0.f;
+    wr[k] = w[k];
+  }
+#pragma unroll
+  for (int k = 0; k < COUT; ++k) pb[k] = 0.f;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    const long b = i / V, v = i - b * V;
+    float g[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      g[co] = dy[(b * COUT + co) * V + v];
+      pb[co] += g[co];
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float xv = x[(b * CIN + ci) * V + v];
+      float s = 0.f;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        s = fmaf(g[co], wr[co * CIN + ci], s);
+        pw[co * CIN + ci] = fmaf(g[co], xv, pw[co * CIN + ci]);
+      }
+      dx[(b * CIN + ci) * V + v] = s;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CIN * COUT; ++k) {
+    float a = pw[k], z = 0.f;
+    block_sum2(a, z, sh);
+    if (threadIdx.x == 0) atomicAdd(dw + k, a);
+  }
+#pragma unroll
+  for (int k = 0; k < COUT; ++k) {
+    float a = pb[k], z = 0.f;
+    block_sum2(a, z, sh);
+    if (threadIdx.x == 0 && db) atomicAdd(db + k, a);
+  }
+}
+
+static unsigned ugrid(long n) { return (unsigned)std::max<long>(1, std::min<long>((n + UT - 1) / UT, 256 * 8)); }
+static unsigned chunks_for(long V, long planes) {
+  // enough blocks to fill the chip without shredding small planes
+  const long want = std::max<long>(1, 2048 / std::max<long>(planes, 1));
+  return (unsigned)std::max<long>(1, std::min<long>(want, (V / 4 + UT - 1) / UT));
+}
+
+}  // namespace hp
+
+using namespace hp;
+
+extern "C" size_t hp_groupnorm_workspace_bytes(int B, int C) { return sizeof(double) * 2 * B * C + sizeof(float) * 3 * B * C; }
+
+// y = relu(GroupNorm(z)); mean/rstd: (B*G) floats saved for backward; workspace: hp_groupnorm_workspace_bytes
+extern "C" int hp_groupnorm_relu_forward(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
+                                         const float* beta, float eps, float* mean, float* rstd, void* workspace,
+                                         void* stream) {
+  HP_REQUIRE(z && y && gamma && beta && mean && rstd && workspace && C % G == 0, "hp_groupnorm_relu_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = (double*)workspace;
+  float* scale = (float*)(acc + 2 * (long)B * C);
+  float* shift = scale + (long)B * C;
+  HP_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * B * C, st));
+  const dim3 grid(chunks_for(V, (long)B * C), (unsigned)(B * C));
+  {
+    HP_PROF("gn_stats", st);
+    hipLaunchKernelGGL(k_plane_stats, grid, dim3(UT), 0, st, z, acc, V);
+  }
+  hipLaunchKernelGGL(k_gn_finalize, dim3((B * C + 127) / 128), dim3(128), 0, st, acc, B, C, G, V, eps, gamma, beta, mean, rstd,
+                     scale, shift);
+  {
+    HP_PROF("gn_apply_relu", st);
+    hipLaunchKernelGGL(k_affine_relu, grid, dim3(UT), 0, st, z, y, scale, shift, V);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_groupnorm_relu_backward(const float* dy, const float* y, const float* z, float* dz, int B, int C, int G,
+                                          long V, const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                                          float* dbeta, void* workspace, void* stream) {
+  HP_REQUIRE(dy && y && z && dz && gamma && mean && rstd && dgamma && dbeta && workspace && C % G == 0,
+             "hp_groupnorm_relu_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = (double*)workspace;
+  float* ca = (float*)(acc + 2 * (long)B * C);
+  float* cb = ca + (long)B * C;
+  float* cc = cb + (long)B * C;
+  HP_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * B * C, st));
+  const dim3 grid(chunks_for(V, (long)B * C), (unsigned)(B * C));
+  {
+    HP_PROF("gn_bwd_reduce", st);
+    hipLaunchKernelGGL(k_gn_bwd_reduce, grid, dim3(UT), 0, st, dy, y, z, acc, V);
+  }
+  hipLaunchKernelGGL(k_gn_bwd_coef, dim3((B * C + 127) / 128), dim3(128), 0, st, acc, B, C, G, V, mean, rstd, gamma, dgamma,
+                     dbeta, ca, cb, cc);
+  {
+    HP_PROF("gn_bwd_apply", st);
+    hipLaunchKernelGGL(k_gn_bwd_apply, grid, dim3(UT), 0, st, dy, y, z, dz, ca, cb, cc, V);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_maxpool3d_k2_forward(const float* x, float* y, long planes, int D, int H, int W, void* stream) {
+  HP_REQUIRE(x && y && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "hp_maxpool3d_k2_forward: even sizes required");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("maxpool2_fwd", st);
+  hipLaunchKernelGGL(k_maxpool2_fwd, dim3(ugrid(planes * (D / 2) * (H / 2) * (W / 2))), dim3(UT), 0, st, x, y, planes, D, H, W);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* dx, long planes, int D, int H, int W,
+                                        void* stream) {
+  HP_REQUIRE(x && dy && dx && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "hp_maxpool3d_k2_backward: even sizes required");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("maxpool2_bwd", st);
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ugrid(planes * (D / 2) * (H / 2) * (W / 2))), dim3(UT), 0, st, x, dy, dx, planes, D, H,
+                     W);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_upsample_trilinear2x_forward(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot,
+                                               int c_off, void* stream) {
+  HP_REQUIRE(x && y && c_off >= 0 && c_off + C <= Ctot, "hp_upsample_trilinear2x_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("upsample2_fwd", st);
+  hipLaunchKernelGGL(k_upsample2_fwd, dim3(ugrid((long)B * C * D * H * W * 8)), dim3(UT), 0, st, x, y, B, C, D, H, W, Ctot, c_off);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_upsample_trilinear2x_backward(const float* dy, float* dx, int B, int C, int D, int H, int W, int Ctot,
+                                                int c_off, void* stream) {
+  HP_REQUIRE(dy && dx && c_off >= 0 && c_off + C <= Ctot, "hp_upsample_trilinear2x_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("upsample2_bwd", st);
+  hipLaunchKernelGGL(k_upsample2_bwd, dim3(ugrid((long)B * C * D * H * W)), dim3(UT), 0, st, dy, dx, B, C, D, H, W, Ctot, c_off);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_channel_slice_copy(const float* src, float* dst, int B, int C, long V, int Ctot, int c_off, int gather,
+                                     void* stream) {
+  HP_REQUIRE(src && dst && V % 4 == 0 && c_off >= 0 && c_off + C <= Ctot, "hp_channel_slice_copy: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("channel_slice_copy", st);
+  hipLaunchKernelGGL(k_channel_slice_copy, dim3(ugrid((long)B * C * V / 4)), dim3(UT), 0, st, src, dst, B, C, V, Ctot, c_off,
+                     gather);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_conv1x1_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout,
+                                  long V, void* stream) {
+  HP_REQUIRE(x && w && y && cin <= 8 && cout <= 8, "hp_conv1x1_forward: at most 8 channels");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("conv1x1_fwd", st);
+  hipLaunchKernelGGL(k_conv1_fwd, dim3(ugrid((long)B * V)), dim3(UT), 0, st, x, w, bias, y, B, cin, cout, V);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_conv1x1_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B,
+                                   int cin, int cout, long V, void* stream) {
+  HP_REQUIRE(x && w && dy && dx && dw, "hp_conv1x1_backward: null argument");
+  if (!(cin == 4 && cout == 1)) {
+    set_error("hp_conv1x1_backward: only the 4 -> 1 output convolution of UNet3d(1,4) is built (got %d -> %d)", cin, cout);
+    return HP_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  HP_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * cin * cout, st));
+  if (db) HP_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * cout, st));
+  HP_PROF("conv1x1_bwd", st);
+  hipLaunchKernelGGL((k_conv1_bwd<4, 1>), dim3(std::min(ugrid((long)B * V), 1024u)), dim3(UT), 0, st, x, w, dy, dx, dw, db, B, V);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}

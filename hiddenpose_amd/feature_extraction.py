@@ -29,8 +29,8 @@ class ResConv3D(nn.Module):
             nn.Identity(), nn.Identity(), nn.Conv3d(basedim, basedim, 3, padding=0, bias=True))
 
     def forward(self, x):
-        h = F.leaky_relu(ops.conv3d_reppad(x, self.tmp[1].weight, self.tmp[1].bias), 0.2)
-        return F.leaky_relu(ops.conv3d_reppad(h, self.tmp[4].weight, self.tmp[4].bias) + x, 0.2)
+        h = ops.leaky_add(ops.conv3d_reppad(x, self.tmp[1].weight, self.tmp[1].bias), None, 0.2)
+        return ops.leaky_add(ops.conv3d_reppad(h, self.tmp[4].weight, self.tmp[4].bias), x, 0.2)
 
 
 class FeatureExtraction(nn.Module):
@@ -49,6 +49,4 @@ class FeatureExtraction(nn.Module):
     def forward(self, x):
         if self.stride == 1 and self.conv1[1].out_channels == 1:
             return ops.feature_extraction_fused(x, self)
-        a = ops.conv3d_reppad(x, self.conv1[1].weight, self.conv1[1].bias, stride=self.stride)
-        a = self.conv1[3](self.conv1[2](a))
-        return a + F.conv3d(x, self.weights, None, stride=self.stride, padding=1)
+        raise NotImplementedError("FeatureExtraction: only stride 1, basedim 1 (the NlosPose configuration) is built")

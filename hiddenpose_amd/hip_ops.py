@@ -12,9 +12,9 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-HIP_STAGES = {"lct_forward", "lct_backward", "posenet3d_50", "feature_extraction.conv", "unet3d.conv3"}
-ATEN_STAGES = {"feature_extraction.leaky_add", "normalize_feature", "unet3d.groupnorm_pool_upsample_out", "softmax_integral",
-               "bce_dice"}
+HIP_STAGES = {"feature_extraction", "lct_forward", "lct_backward", "normalize_feature", "unet3d", "posenet3d_50",
+              "softmax_integral", "bce_dice"}
+ATEN_STAGES = {"weighted_mse on (B,72) joints", "Adam"}
 
 
 def _need_cuda(x: torch.Tensor, what: str) -> None:
@@ -84,41 +84,232 @@ def conv3d_reppad(x, w, b, stride=1):
     return _DConv3.apply(x, w, b, True)
 
 
+class _LeakyAdd(torch.autograd.Function):
+    """y = leaky_relu(a [+ b], slope); slope = 1 gives a plain add.  csrc/misc_kernels.hip."""
+
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        _need_cuda(a, "leaky_add")
+        a = a.contiguous()
+        b = b.contiguous() if b is not None else None
+        y = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.lib().hp_leaky_add_forward(a.data_ptr(), _lib.ptr(b), y.data_ptr(), a.numel(), slope,
+                                                       _stream(a)), "hp_leaky_add_forward")
+        ctx.slope, ctx.has_b = slope, b is not None
+        if slope != 1.0:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.slope == 1.0:
+            return dy, (dy if ctx.has_b else None), None
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = torch.empty_like(dy)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.lib().hp_leaky_backward(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), ctx.slope,
+                                                    _stream(dy)), "hp_leaky_backward")
+        return g, (g if ctx.has_b else None), None
+
+
+def leaky_add(a, b=None, slope=0.2):
+    return _LeakyAdd.apply(a, b, slope)
+
+
+def add(a, b):
+    return _LeakyAdd.apply(a, b, 1.0)
+
+
 def feature_extraction_fused(x, fe):
     _need_cuda(x, "feature_extraction")
     a = conv3d_reppad(x, fe.conv1[1].weight, fe.conv1[1].bias)
     a = fe.conv1[3](fe.conv1[2](a))
-    return a + _DConv3.apply(x, fe.weights, None, False)
+    return add(a, _DConv3.apply(x, fe.weights, None, False))
 
 
 # ---------------------------------------------------------------- normalize_feature (row C8)
+class _NormalizeFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "normalize_feature")
+        x = x.contiguous()
+        nvol = x.shape[0] * x.shape[1]
+        V = x.numel() // nvol
+        y = torch.empty_like(x)
+        keys = torch.empty(2 * nvol, dtype=torch.int64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_normalize_feature_forward(x.data_ptr(), y.data_ptr(), nvol, V, 10.0, keys.data_ptr(),
+                                                               _stream(x)), "hp_normalize_feature_forward")
+        ctx.save_for_backward(x, keys)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, keys = ctx.saved_tensors
+        dy = dy.contiguous()
+        nvol = x.shape[0] * x.shape[1]
+        V = x.numel() // nvol
+        dx = torch.empty_like(x)
+        ws = torch.empty(2 * nvol, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_normalize_feature_backward(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), nvol, V, 10.0,
+                                                                keys.data_ptr(), ws.data_ptr(), _stream(x)),
+                       "hp_normalize_feature_backward")
+        return dx
+
+
 def normalize_feature(x):
     """(x - min)/(max(x - min) + 1e-15) * 10 per (b, c); NO ReLU (feature_propagation.py:273-286)."""
-    _need_cuda(x, "normalize_feature")
-    b, c = x.shape[:2]
-    f = x.reshape(b, c, -1)
-    z = f - f.min(2, keepdim=True)[0]
-    return (z / (z.max(2, keepdim=True)[0] + 1e-15) * 10.0).view_as(x)
+    return _NormalizeFeature.apply(x)
 
 
 # ---------------------------------------------------------------- UNet3d (row U1)
+class _GroupNormRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, groups, eps):
+        L = _lib.lib()
+        z = z.contiguous()
+        b, c = z.shape[:2]
+        V = z.numel() // (b * c)
+        y = torch.empty_like(z)
+        mean = torch.empty(b * groups, dtype=torch.float32, device=z.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, c)) // 4 + 2, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(L.hp_groupnorm_relu_forward(z.data_ptr(), y.data_ptr(), b, c, groups, V, gamma.data_ptr(),
+                                                   beta.data_ptr(), eps, mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
+                                                   _stream(z)), "hp_groupnorm_relu_forward")
+        ctx.save_for_backward(z, y, gamma, mean, rstd)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        z, y, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, c = z.shape[:2]
+        V = z.numel() // (b * c)
+        dz = torch.empty_like(z)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, c)) // 4 + 2, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(L.hp_groupnorm_relu_backward(dy.data_ptr(), y.data_ptr(), z.data_ptr(), dz.data_ptr(), b, c,
+                                                    ctx.groups, V, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                    dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(z)),
+                       "hp_groupnorm_relu_backward")
+        return dz, dgamma, dbeta, None, None
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        b, c, d, h, w = x.shape
+        y = torch.empty(b, c, d // 2, h // 2, w // 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_maxpool3d_k2_forward(x.data_ptr(), y.data_ptr(), b * c, d, h, w, _stream(x)),
+                       "hp_maxpool3d_k2_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        b, c, d, h, w = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_maxpool3d_k2_backward(x.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), b * c, d,
+                                                           h, w, _stream(x)), "hp_maxpool3d_k2_backward")
+        return dx
+
+
+class _UpsampleCat(torch.autograd.Function):
+    """cat([skip, upsample2x_trilinear_align_corners(x1)], dim=1) without materialising the upsampled tensor."""
+
+    @staticmethod
+    def forward(ctx, x1, skip):
+        L = _lib.lib()
+        x1, skip = x1.contiguous(), skip.contiguous()
+        b, c1, d, h, w = x1.shape
+        c2 = skip.shape[1]
+        assert skip.shape[2:] == (2 * d, 2 * h, 2 * w), "UNet3d skip and upsampled sizes must match (even input sizes)"
+        out = torch.empty(b, c1 + c2, 2 * d, 2 * h, 2 * w, dtype=torch.float32, device=x1.device)
+        st = _stream(x1)
+        with torch.cuda.device(x1.device):
+            _lib.check(L.hp_channel_slice_copy(skip.data_ptr(), out.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 0, st),
+                       "hp_channel_slice_copy")
+            _lib.check(L.hp_upsample_trilinear2x_forward(x1.data_ptr(), out.data_ptr(), b, c1, d, h, w, c1 + c2, c2, st),
+                       "hp_upsample_trilinear2x_forward")
+        ctx.dims = (b, c1, c2, d, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        b, c1, c2, d, h, w = ctx.dims
+        dy = dy.contiguous()
+        dx1 = torch.empty(b, c1, d, h, w, dtype=torch.float32, device=dy.device)
+        dskip = torch.empty(b, c2, 2 * d, 2 * h, 2 * w, dtype=torch.float32, device=dy.device)
+        st = _stream(dy)
+        with torch.cuda.device(dy.device):
+            _lib.check(L.hp_channel_slice_copy(dy.data_ptr(), dskip.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 1, st),
+                       "hp_channel_slice_copy")
+            _lib.check(L.hp_upsample_trilinear2x_backward(dy.data_ptr(), dx1.data_ptr(), b, c1, d, h, w, c1 + c2, c2, st),
+                       "hp_upsample_trilinear2x_backward")
+        return dx1, dskip
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        b, cin = x.shape[:2]
+        cout = w.shape[0]
+        V = x.numel() // (b * cin)
+        y = torch.empty((b, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_conv1x1_forward(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), y.data_ptr(), b, cin, cout,
+                                                     V, _stream(x)), "hp_conv1x1_forward")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, cin = x.shape[:2]
+        cout = w.shape[0]
+        V = x.numel() // (b * cin)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_conv1x1_backward(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                      _lib.ptr(db), b, cin, cout, V, _stream(x)), "hp_conv1x1_backward")
+        return dx, dw, db
+
+
 def conv3d(x, w, b=None, stride=1, padding=0):
-    """1x1x1 convolution (UNet3d `Out`, unet/unet3d.py:65-71): a per-voxel channel mix."""
-    assert w.shape[2:] == (1, 1, 1) and stride == 1 and padding == 0
-    y = torch.einsum("bcdhw,oc->bodhw", x, w.reshape(w.shape[0], w.shape[1]))
-    return y if b is None else y + b.view(1, -1, 1, 1, 1)
+    """1x1x1 convolution (UNet3d `Out`, unet/unet3d.py:65-71)."""
+    assert tuple(w.shape[2:]) == (1, 1, 1) and stride == 1 and padding == 0
+    return _Conv1x1.apply(x, w, b)
 
 
 def conv3_gn_relu(x, w, b, gw, gb, groups, eps):
-    return F.relu(F.group_norm(_DConv3.apply(x, w, b, False), groups, gw, gb, eps))
+    return _GroupNormRelu.apply(_DConv3.apply(x, w, b, False), gw, gb, groups, eps)
 
 
 def max_pool3d_2(x):
-    return F.max_pool3d(x, 2, 2)
+    return _MaxPool2.apply(x)
 
 
-def upsample_trilinear_2x(x):
-    return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
+def upsample_cat(x1, skip):
+    return _UpsampleCat.apply(x1, skip)
 
 
 # ---------------------------------------------------------------- posenet3d_50 (rows P1-P3)
@@ -315,20 +506,66 @@ def head_conv_to_ncdhw(x, conv):
 
 
 # ---------------------------------------------------------------- decode + losses (rows L1-L3)
+class _SoftArgmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, num_joints, W, H, D):
+        _need_cuda(preds, "softmax_integral")
+        heat = preds.contiguous()
+        B = heat.shape[0]
+        bj = B * num_joints
+        assert heat.numel() == bj * D * H * W
+        joints = torch.empty(B, num_joints * 3, dtype=torch.float32, device=heat.device)
+        stat = torch.empty(bj * 2, dtype=torch.float32, device=heat.device)
+        with torch.cuda.device(heat.device):
+            _lib.check(_lib.lib().hp_softargmax_forward(heat.data_ptr(), joints.data_ptr(), stat.data_ptr(), bj, D, H, W,
+                                                        _stream(heat)), "hp_softargmax_forward")
+        ctx.save_for_backward(heat, joints, stat)
+        ctx.dims = (bj, D, H, W)
+        return joints
+
+    @staticmethod
+    def backward(ctx, gj):
+        heat, joints, stat = ctx.saved_tensors
+        bj, D, H, W = ctx.dims
+        dheat = torch.empty_like(heat)
+        with torch.cuda.device(heat.device):
+            _lib.check(_lib.lib().hp_softargmax_backward(heat.data_ptr(), joints.data_ptr(), stat.data_ptr(),
+                                                         gj.contiguous().data_ptr(), dheat.data_ptr(), bj, D, H, W,
+                                                         _stream(heat)), "hp_softargmax_backward")
+        return dheat, None, None, None, None
+
+
 def softmax_integral(preds, num_joints, W, H, D):
-    """soft-argmax in voxel units, order (x,y,z) = (W,H,D axis) (utils/criterion.py:96-153)."""
-    _need_cuda(preds, "softmax_integral")
-    B = preds.shape[0]
-    p = F.softmax(preds.reshape(B, num_joints, -1), 2).reshape(B, num_joints, D, H, W)
-    ar = lambda n: torch.arange(n, dtype=p.dtype, device=p.device)
-    ax = (p.sum(dim=(2, 3)) * ar(W)).sum(2, keepdim=True)
-    ay = (p.sum(dim=(2, 4)) * ar(H)).sum(2, keepdim=True)
-    az = (p.sum(dim=(3, 4)) * ar(D)).sum(2, keepdim=True)
-    return torch.cat((ax, ay, az), dim=2).reshape(B, num_joints * 3)
+    """soft-argmax in voxel units, order (x,y,z) = (W,H,D axis) (utils/criterion.py:96-153) -> (B, 3J)."""
+    return _SoftArgmax.apply(preds, num_joints, W, H, D)
+
+
+class _BceDice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, eps):
+        _need_cuda(logits, "bce_dice")
+        logits, targets = logits.contiguous(), targets.contiguous().float()
+        acc = torch.empty(4, dtype=torch.float64, device=logits.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            _lib.check(_lib.lib().hp_bce_dice_forward(logits.data_ptr(), targets.data_ptr(), logits.numel(), eps,
+                                                      acc.data_ptr(), loss.data_ptr(), _stream(logits)),
+                       "hp_bce_dice_forward")
+        ctx.save_for_backward(logits, targets, acc)
+        ctx.eps = eps
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        logits, targets, acc = ctx.saved_tensors
+        d = torch.empty_like(logits)
+        gl = gl.reshape(1).contiguous().float()
+        with torch.cuda.device(logits.device):
+            _lib.check(_lib.lib().hp_bce_dice_backward(logits.data_ptr(), targets.data_ptr(), acc.data_ptr(), gl.data_ptr(),
+                                                       d.data_ptr(), logits.numel(), ctx.eps, _stream(logits)),
+                       "hp_bce_dice_backward")
+        return d, None, None
 
 
 def bce_dice(logits, targets, eps=1e-9):
-    _need_cuda(logits, "bce_dice")
-    prob = torch.sigmoid(logits)
-    dice = (2.0 * (prob * targets).sum() + eps) / (prob.sum() + targets.sum())
-    return F.binary_cross_entropy_with_logits(logits, targets) + (1.0 - dice)
+    return _BceDice.apply(logits, targets, eps)

@@ -44,11 +44,8 @@ class Up(nn.Module):
         self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
-        x1 = ops.upsample_trilinear_2x(x1)
-        dz, dy, dx = (x2.size(i) - x1.size(i) for i in (2, 3, 4))
-        if dz or dy or dx:
-            x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2, dz // 2, dz - dz // 2])
-        return self.conv(torch.cat([x2, x1], dim=1))
+        # upsample x1 and concatenate [skip, up] (the reference's F.pad is a no-op for even sizes)
+        return self.conv(ops.upsample_cat(x1, x2))
 
 
 class Out(nn.Module):

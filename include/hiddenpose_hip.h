@@ -149,6 +149,57 @@ int hp_dconv3_backward_data(const float* gy, const float* w, float* gx, int B, i
 int hp_dconv3_backward_weight(const float* x, const float* gy, float* dw, float* dbias, int B, int cin, int cout, int D,
                               int H, int W, int replicate_pad, void* stream);
 
+/* ------------------------------------------------------------------------
+ * UNet3d memory-bound stages (unet/unet3d.py), planar (B, C, D, H, W) fp32; V = D*H*W.
+ * ---------------------------------------------------------------------- */
+size_t hp_groupnorm_workspace_bytes(int B, int C);
+/* y = relu(GroupNorm_G(z) * gamma + beta)  (unet3d.py:17-18,22-23); mean/rstd: B*G floats kept for backward */
+int hp_groupnorm_relu_forward(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
+                              const float* beta, float eps, float* mean, float* rstd, void* workspace, void* stream);
+int hp_groupnorm_relu_backward(const float* dy, const float* y, const float* z, float* dz, int B, int C, int G, long V,
+                               const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                               void* workspace, void* stream);
+/* MaxPool3d(2,2) (unet3d.py:35); planes = B*C */
+int hp_maxpool3d_k2_forward(const float* x, float* y, long planes, int D, int H, int W, void* stream);
+int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* dx, long planes, int D, int H, int W, void* stream);
+/* nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True) (unet3d.py:47), written into /
+ * read from channel slice [c_off, c_off+C) of a (B, Ctot, 2D, 2H, 2W) tensor: the torch.cat of :61 */
+int hp_upsample_trilinear2x_forward(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot, int c_off,
+                                    void* stream);
+int hp_upsample_trilinear2x_backward(const float* dy, float* dx, int B, int C, int D, int H, int W, int Ctot, int c_off,
+                                     void* stream);
+/* (B,C,V) -> channel slice of (B,Ctot,V) (gather = 0) or the reverse (gather = 1) */
+int hp_channel_slice_copy(const float* src, float* dst, int B, int C, long V, int Ctot, int c_off, int gather,
+                          void* stream);
+/* 1x1x1 convolution of UNet3d's `Out` (unet3d.py:65-71) */
+int hp_conv1x1_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, long V,
+                       void* stream);
+int hp_conv1x1_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int cin,
+                        int cout, long V, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Elementwise / reduction stages around the convolutions.
+ * ---------------------------------------------------------------------- */
+/* y = leaky_relu(a [+ b], slope); slope = 1 is a plain add (feature_extraction.py:170,252-255; NlosPose.py:57) */
+int hp_leaky_add_forward(const float* a, const float* b, float* y, long n, float slope, void* stream);
+int hp_leaky_backward(const float* dy, const float* y, float* g, long n, float slope, void* stream);
+/* normalize_feature (feature_propagation.py:273-286): per volume (x - min)/(max(x - min) + 1e-15) * gain, NO ReLU.
+ * keys: 2*nvol uint64 (min/max value+index) kept for backward; backward workspace: 2*nvol doubles */
+int hp_normalize_feature_forward(const float* x, float* y, int nvol, long V, float gain, void* keys, void* stream);
+int hp_normalize_feature_backward(const float* dy, const float* x, float* dx, int nvol, long V, float gain,
+                                  const void* keys, void* workspace, void* stream);
+/* softmax_integral_tensor (utils/criterion.py:96-153): heat (BJ, D, H, W) -> joints (BJ, 3) = E[w], E[h], E[d]
+ * in voxel units; stat: 2*BJ floats (max, sum) kept for backward */
+int hp_softargmax_forward(const float* heat, float* joints, float* stat, int BJ, int D, int H, int W, void* stream);
+int hp_softargmax_backward(const float* heat, const float* joints, const float* stat, const float* gjoints, float* dheat,
+                           int BJ, int D, int H, int W, void* stream);
+/* BCEDiceLoss (utils/criterion.py:348-385): BCEWithLogits(mean) + 1 - (2 sum(sig t) + eps)/(sum sig + sum t) over all
+ * n elements.  acc: 4 doubles kept for backward. */
+int hp_bce_dice_forward(const float* logit, const float* target, long n, float eps, double* acc, float* loss,
+                        void* stream);
+int hp_bce_dice_backward(const float* logit, const float* target, const double* acc, const float* gloss, float* dlogit,
+                         long n, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
