@@ -18,6 +18,7 @@
 // Epilogue: optional bias, per-channel sum / sum-of-squares for train-mode BatchNorm
 // (fp64 atomics, one pair per column per block), 128-byte coalesced channels-last stores.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -290,62 +291,79 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
 // A = dY^T tile, B = gathered X tile; both are staged exactly as they lie in memory
 // ([m][channel]), which is already the conflict-free MFMA fragment order.  The voxel range
 // is split over blockIdx.z; partial tiles are combined with fp32 atomics.
-constexpr int WG_T = 64;   // dW tile: 64 (n) x 64 (c)
 constexpr int WG_KM = 32;  // voxels per step
 
-template <bool STEM>
+// TT x TT weight tile per workgroup (TT = 128: 2x2 MFMA tiles per wave; TT = 64: one), 32 voxels per
+// step, global loads of step s+1 in flight while the MFMAs of step s run.  With TT = 64 a block may own
+// NTAP consecutive taps of a single-class convolution: the dY tile is staged once and reused by the
+// NTAP gathered X tiles (1 + NTAP LDS fragment reads feed NTAP MFMAs).
+template <bool STEM, int TT, int NTAP>
 __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
-                                              float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit,
-                                              int ntap_total) {
-  __shared__ float Ys[WG_KM * WG_T];
-  __shared__ float Xs[WG_KM * WG_T];
+                                              float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit) {
+  constexpr int QN = TT / 4;            // float4 per staged row
+  constexpr int RPP = CT / QN;          // rows per staging pass
+  constexpr int RPT = WG_KM / RPP;      // rows per thread
+  constexpr int WT = TT / 64;           // 32x32 tiles per wave per dim
+  static_assert(NTAP == 1 || TT == 64, "multi-tap blocks use the 64x64 tile");
+  __shared__ float Ys[WG_KM * TT];
+  __shared__ float Xs[NTAP * WG_KM * TT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile_n = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
-  const int n0 = tile_n * WG_T, c0 = tile_c * WG_T;
-  // blockIdx.y enumerates (class, tap)
-  int cls = 0, tap = blockIdx.y;
-  if (!STEM) {
+  const int n0 = tile_n * TT, c0 = tile_c * TT;
+  int cls = 0, tap = blockIdx.y * NTAP;  // blockIdx.y enumerates (class, tap group)
+  if (!STEM && NTAP == 1) {
     while (tap >= class_ntaps(g, cls)) {
       tap -= class_ntaps(g, cls);
       ++cls;
     }
   }
-  (void)ntap_total;
+  const int ntaps_cls = STEM ? 1 : class_ntaps(g, cls);
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-  int dz = 0, dy = 0, dx = 0, widx = 0;
-  if (!STEM) tap_info(g, cls, tap, dz, dy, dx, widx);
+  int dz[NTAP], dy[NTAP], dx[NTAP], widx[NTAP];
+  bool tv[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    dz[t] = dy[t] = dx[t] = widx[t] = 0;
+    tv[t] = tap + t < ntaps_cls;
+    if (!STEM && tv[t]) tap_info(g, cls, tap + t, dz[t], dy[t], dx[t], widx[t]);
+  }
   const long chunk = ((g.M + msplit - 1) / msplit + WG_KM - 1) / WG_KM * WG_KM;
   const long mbeg = (long)blockIdx.z * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
   const int Kc = STEM ? g.kpt * BK : g.Cin;  // extent of the c axis
-
-  // staging: 32 rows x 64 floats = 512 float4 -> 2 per thread for each operand
-  const int sr = tid >> 4, sq = tid & 15;  // rows sr, sr+16 ; float4 column sq
-  // wave tile: 2x2 waves of 32x32
+  const int sq = tid % QN, sr = tid / QN;
   const int wn = wave >> 1, wc = wave & 1;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (long mb = mbeg; mb < mend; mb += WG_KM) {
-    float4 vy[2], vx[2];
+  f32x16 acc[NTAP][WT][WT];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const long m = mb + sr + 16 * h;
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  float4 vy[RPT], vx[NTAP][RPT];
+  auto load_step = [&](long mb) {
+#pragma unroll
+    for (int h = 0; h < RPT; ++h) {
+      const long m = mb + sr + RPP * h;
       vy[h] = make_float4(0, 0, 0, 0);
-      vx[h] = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) vx[t][h] = make_float4(0, 0, 0, 0);
       if (m < mend) {
-        long t = m;
-        const int x = (int)(t % g.gw);
-        t /= g.gw;
-        const int y = (int)(t % g.gh);
-        t /= g.gh;
-        const int z = (int)(t % g.gd);
-        const int b = (int)(t / g.gd);
+        long tt = m;
+        const int x = (int)(tt % g.gw);
+        tt /= g.gw;
+        const int y = (int)(tt % g.gh);
+        tt /= g.gh;
+        const int z = (int)(tt % g.gd);
+        const int b = (int)(tt / g.gd);
         const long orow = (((long)b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw;
         const int n = n0 + sq * 4;
         if (n + 3 < g.Nout) {
           vy[h] = *(const float4*)(dY + orow * g.Nout + n);
-        } else {
+        } else if (n < g.Nout) {
           float t4[4] = {0, 0, 0, 0};
           for (int e = 0; e < 4; ++e)
             if (n + e < g.Nout) t4[e] = dY[orow * g.Nout + n + e];
@@ -362,40 +380,67 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
                             (unsigned)xx < (unsigned)g.Wi;
             t4[e] = ok ? X[(((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx] : 0.f;
           }
-          vx[h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+          vx[0][h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         } else {
-          const int zz = z * g.s + dz, yy = y * g.s + dy, xx = x * g.s + dx;
           const int c = c0 + sq * 4;
-          if ((unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
-              c < g.Cin)
-            vx[h] = *(const float4*)(X + ((((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) {
+            const int zz = z * g.s + dz[t], yy = y * g.s + dy[t], xx = x * g.s + dx[t];
+            if (tv[t] && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
+                c < g.Cin)
+              vx[t][h] = *(const float4*)(X + ((((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
+          }
         }
       }
     }
-    __syncthreads();  // previous step's fragment reads are done
+  };
+
+  if (mbeg < mend) load_step(mbeg);
+  for (long mb = mbeg; mb < mend; mb += WG_KM) {
+    __syncthreads();  // fragment reads of the previous step are done
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *(float4*)(Ys + (sr + 16 * h) * WG_T + sq * 4) = vy[h];
-      *(float4*)(Xs + (sr + 16 * h) * WG_T + sq * 4) = vx[h];
+    for (int h = 0; h < RPT; ++h) {
+      *(float4*)(Ys + (sr + RPP * h) * TT + sq * 4) = vy[h];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) *(float4*)(Xs + (t * WG_KM + sr + RPP * h) * TT + sq * 4) = vx[t][h];
     }
     __syncthreads();
+    if (mb + WG_KM < mend) load_step(mb + WG_KM);
 #pragma unroll
     for (int kk = 0; kk < WG_KM / 2; ++kk) {
       const int mrow = 2 * kk + (lane >> 5);
-      const float a = Ys[mrow * WG_T + wn * 32 + (lane & 31)];
-      const float b = Xs[mrow * WG_T + wc * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[WT], b[NTAP][WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[i] = Ys[mrow * TT + wn * (TT / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) b[t][j] = Xs[(t * WG_KM + mrow) * TT + wc * (TT / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
     }
   }
   // dW layout: [slab][n][Kc]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int c = c0 + wc * 32 + (lane & 31);
-    if (n < g.Nout && c < Kc) atomicAdd(dW + ((long)widx * g.Nout + n) * Kc + c, acc[r]);
+  for (int t = 0; t < NTAP; ++t) {
+    if (!tv[t]) continue;
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wn * (TT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int c = c0 + wc * (TT / 2) + j * 32 + (lane & 31);
+          if (n < g.Nout && c < Kc) atomicAdd(dW + ((long)widx[t] * g.Nout + n) * Kc + c, acc[t][i][j][r]);
+        }
   }
 }
-
 
 // ---------------------------------------------------------------- stem data gradient
 // dX[j + k - 3] += sum_n dZ[j][n] * w[n][k]   (7^3 taps, 64 channels -> 1 channel)
@@ -408,7 +453,8 @@ constexpr int SR_Z = SP_Z + 6, SR_Y = SP_Y + 6, SR_X = SP_X + 6, SR_N = SR_Z * S
 constexpr int SLD = 65;
 
 __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
-                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px) {
+                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px,
+                                                   int dbg) {
   __shared__ float As[SP_M * SLD];
   __shared__ float Bs[32 * SLD];
   __shared__ float patch[SR_N];
@@ -471,7 +517,7 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk], acc, 0, 0, 0);
     const int tap = chunk * 32 + (lane & 31);
-    if (tap < 343) {
+    if (tap < 343 && !(dbg & 1)) {
       const int kd = tap / 49, kh = (tap / 7) % 7, kw = tap % 7;
       const int toff = (kd * SR_Y + kh) * SR_X + kw;
 #pragma unroll
@@ -482,7 +528,7 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   for (int i = tid; i < SR_N; i += CT) {
     const int cz = i / (SR_Y * SR_X), cy = (i / SR_X) % SR_Y, cx = i % SR_X;
     const int z = z0 + cz - 3, y = y0 + cy - 3, x = x0 + cx - 3;
-    if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+    if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && !(dbg & 2))
       atomicAdd(dX + (((long)b * D + z) * H + y) * W + x, patch[i]);
   }
 }
@@ -701,8 +747,9 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
     HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi, st));
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     HP_PROF("conv_stem_dgrad", st);
+    static const int dbg = getenv("HP_DEBUG_STEM") ? atoi(getenv("HP_DEBUG_STEM")) : 0;
     hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, dy, w_dgrad, dx,
-                       d->Di, d->Hi, d->Wi, pz, py, px);
+                       d->Di, d->Hi, d->Wi, pz, py, px, dbg);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
@@ -726,16 +773,22 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
   const IgemmGeom& g = p.wgrad;
   const int Kc = p.stem ? g.kpt * BK : g.Cin;
   HP_CHECK_HIP(hipMemsetAsync(dw_packed, 0, sizeof(float) * hp_conv3d_packed_weight_elems(d), st));
-  const int tiles_n = (g.Nout + WG_T - 1) / WG_T, tiles_c = (Kc + WG_T - 1) / WG_T;
-  const long base_blocks = (long)tiles_n * tiles_c * p.wgrad_tapsum;
-  long msplit = std::max<long>(1, (2048 + base_blocks - 1) / base_blocks);
+  const int TT = (g.Nout >= 128 && Kc >= 128) ? 128 : 64;
+  // 64-wide tiles of a plain 3^3 convolution: 4 taps per block share the staged dY tile
+  const bool multitap = !p.stem && TT == 64 && g.mode == MODE_CONV && g.k == 3;
+  const int tap_groups = multitap ? (27 + 3) / 4 : p.wgrad_tapsum;
+  const int tiles_n = (g.Nout + TT - 1) / TT, tiles_c = (Kc + TT - 1) / TT;
+  const long base_blocks = (long)tiles_n * tiles_c * tap_groups;
+  long msplit = std::max<long>(1, (1536 + base_blocks - 1) / base_blocks);
   msplit = std::min<long>(msplit, std::max<long>(1, g.M / (4 * WG_KM)));
   msplit = std::min<long>(msplit, 4096);
-  dim3 grid((unsigned)(tiles_n * tiles_c), (unsigned)p.wgrad_tapsum, (unsigned)msplit);
+  dim3 grid((unsigned)(tiles_n * tiles_c), (unsigned)tap_groups, (unsigned)msplit);
   {
     HP_PROF("conv_wgrad", st);
-    if (p.stem) hipLaunchKernelGGL((k_wgrad<true>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, p.wgrad_tapsum);
-    else hipLaunchKernelGGL((k_wgrad<false>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, p.wgrad_tapsum);
+    if (p.stem) hipLaunchKernelGGL((k_wgrad<true, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
+    else if (TT == 128) hipLaunchKernelGGL((k_wgrad<false, 128, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
+    else if (multitap) hipLaunchKernelGGL((k_wgrad<false, 64, 4>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
+    else hipLaunchKernelGGL((k_wgrad<false, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
