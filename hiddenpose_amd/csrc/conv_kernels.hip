@@ -445,18 +445,24 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
 // ---------------------------------------------------------------- stem data gradient
 // dX[j + k - 3] += sum_n dZ[j][n] * w[n][k]   (7^3 taps, 64 channels -> 1 channel)
 // As an implicit GEMM this has N = 1, so it is computed the other way round: per 4x4x8 voxel
-// patch P[j][k] = dZ[j][:] . w[:][k] is a dense 128 x 343 x 64 GEMM on the matrix cores, and the
-// 343 columns are scatter-added (col2im) into a 10x10x14 LDS patch that is flushed to dX
-// with one fp32 atomic per touched voxel.
+// patch, P[j][k] = dZ[j][:] . w[:][k] is a dense 128 x 64 GEMM per tap chunk on the matrix
+// cores, followed by a col2im fold of the tap columns into a 10x10x14 LDS patch that is
+// flushed to dX with one fp32 atomic per touched voxel.
+// LDS float atomics are ~100x slower than plain LDS traffic on gfx950, so the fold is a
+// gather: a chunk is (one kd) x (4 kh) x (7 kw, padded to 8) = 32 columns; each wave (one z slice
+// of the patch) parks its 32x32 P tile in a staging array addressed by OUTPUT cell
+// [kh][jy][cx = jx + kw][kw], then every lane owns output cells and sums their <= 4 x 7 terms.
 constexpr int SP_Z = 4, SP_Y = 4, SP_X = 8, SP_M = SP_Z * SP_Y * SP_X;  // 128 voxels
 constexpr int SR_Z = SP_Z + 6, SR_Y = SP_Y + 6, SR_X = SP_X + 6, SR_N = SR_Z * SR_Y * SR_X;
 constexpr int SLD = 65;
+constexpr int SG_KW = 9;                                  // padded kw slots per cell
+constexpr int SG_N = 4 * SP_Y * SR_X * SG_KW;             // staging floats per wave
 
 __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
-                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px,
-                                                   int dbg) {
+                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px) {
   __shared__ float As[SP_M * SLD];
   __shared__ float Bs[32 * SLD];
+  __shared__ float stage[4 * SG_N];
   __shared__ float patch[SR_N];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x;
@@ -468,8 +474,7 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   const int b = blockIdx.y;
   const int z0 = bz * SP_Z, y0 = by * SP_Y, x0 = bx * SP_X;
   for (int i = tid; i < SR_N; i += CT) patch[i] = 0.f;
-  // A tile: 128 voxels x 64 channels
-  {
+  {  // A tile: 128 voxels x 64 channels
     const int q = tid & 15, r0 = tid >> 4;
 #pragma unroll
     for (int pss = 0; pss < SP_M / 16; ++pss) {
@@ -485,25 +490,22 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
       d[3] = v.w;
     }
   }
-  // static scatter geometry of this lane's 16 accumulator rows
-  int cell_row[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int rz = row / (SP_Y * SP_X), ry = (row / SP_X) % SP_Y, rx = row % SP_X;
-    cell_row[r] = (rz * SR_Y + ry) * SR_X + rx;
-  }
   const float* ap = As + (wave * 32 + (lane & 31)) * SLD + (lane >> 5);
   const float* bp = Bs + (lane & 31) * SLD + (lane >> 5);
-  for (int chunk = 0; chunk < 11; ++chunk) {
-    __syncthreads();  // previous chunk's fragment reads are finished (and As / patch are ready)
+  float* sw = stage + wave * SG_N;
+  const int col = lane & 31, gi_l = col >> 3, kw_l = col & 7, half = lane >> 5;
+  // staging write address of accumulator register r: lane part + compile-time register part
+  const int sw_lane = ((gi_l * SP_Y) * SR_X + 4 * half + kw_l) * SG_KW + kw_l;
+  for (int chunk = 0; chunk < 14; ++chunk) {
+    const int kd = chunk >> 1, kh0 = (chunk & 1) * 4, npair = (chunk & 1) ? 3 : 4;
+    __syncthreads();  // previous chunk: fragment reads, gather reads and patch updates are finished
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int i = tid + h * CT;  // 512 float4 = 32 taps x 16 quads
+      const int i = tid + h * CT;  // 512 float4 = 32 columns x 16 quads
       const int tr = i >> 4, q = i & 15;
-      const int tap = chunk * 32 + tr;
+      const int gi = tr >> 3, kw = tr & 7;
       float4 v = make_float4(0, 0, 0, 0);
-      if (tap < 343) v = *(const float4*)(Wt + (long)tap * 64 + q * 4);
+      if (gi < npair && kw < 7) v = *(const float4*)(Wt + (long)(((kd * 7) + kh0 + gi) * 7 + kw) * 64 + q * 4);
       float* d = Bs + tr * SLD + q * 4;
       d[0] = v.x;
       d[1] = v.y;
@@ -516,19 +518,40 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk], acc, 0, 0, 0);
-    const int tap = chunk * 32 + (lane & 31);
-    if (tap < 343 && !(dbg & 1)) {
-      const int kd = tap / 49, kh = (tap / 7) % 7, kw = tap % 7;
-      const int toff = (kd * SR_Y + kh) * SR_X + kw;
+    // park P: register r is voxel (jy = r>>2, jx = (r&3) + 4*half) of this wave's z slice
+    if (kw_l < 7 && gi_l < npair) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(&patch[cell_row[r] + toff], acc[r]);
+      for (int r = 0; r < 16; ++r) sw[sw_lane + ((r >> 2) * SR_X + (r & 3)) * SG_KW] = acc[r];
+    }
+    __syncthreads();
+    // fold: cell (cyr in 0..6, cx in 0..13) of plane cz = wave + kd
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int cell = lane + 64 * pass;
+      if (cell < 7 * SR_X) {
+        const int cyr = cell / SR_X, cx = cell - cyr * SR_X;
+        float sum = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          const int jy = cyr - gi;
+          if (gi < npair && jy >= 0 && jy < SP_Y) {
+            const float* sp = sw + ((gi * SP_Y + jy) * SR_X + cx) * SG_KW;
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+              const int jx = cx - kw;
+              if (jx >= 0 && jx < SP_X) sum += sp[kw];
+            }
+          }
+        }
+        patch[((wave + kd) * SR_Y + kh0 + cyr) * SR_X + cx] += sum;
+      }
     }
   }
   __syncthreads();
   for (int i = tid; i < SR_N; i += CT) {
     const int cz = i / (SR_Y * SR_X), cy = (i / SR_X) % SR_Y, cx = i % SR_X;
     const int z = z0 + cz - 3, y = y0 + cy - 3, x = x0 + cx - 3;
-    if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && !(dbg & 2))
+    if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
       atomicAdd(dX + (((long)b * D + z) * H + y) * W + x, patch[i]);
   }
 }
@@ -747,9 +770,8 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
     HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi, st));
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     HP_PROF("conv_stem_dgrad", st);
-    static const int dbg = getenv("HP_DEBUG_STEM") ? atoi(getenv("HP_DEBUG_STEM")) : 0;
     hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, dy, w_dgrad, dx,
-                       d->Di, d->Hi, d->Wi, pz, py, px, dbg);
+                       d->Di, d->Hi, d->Wi, pz, py, px);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
