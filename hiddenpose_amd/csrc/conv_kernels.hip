@@ -39,7 +39,27 @@ struct IgemmGeom {
   int k, s, p, flip;       // MODE_CONV: gathered pos = g*s + (flip ? p - kk : kk - p)
   long M;                  // B*gd*gh*gw
   int kpt;                 // K tiles per tap (Cin/32, or padded taps/32 for the stem)
+  int sw, sh, sd;          // log2 of gw, gh, gd when all three are powers of two, else -1
 };
+
+// m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
+__device__ __forceinline__ void grid_coords(const IgemmGeom& g, long m, int& b, int& z, int& y, int& x) {
+  if (g.sw >= 0) {
+    const unsigned int u = (unsigned int)m;  // M < 2^32 is checked on the host for this path
+    x = (int)(u & (unsigned)(g.gw - 1));
+    y = (int)((u >> g.sw) & (unsigned)(g.gh - 1));
+    z = (int)((u >> (g.sw + g.sh)) & (unsigned)(g.gd - 1));
+    b = (int)(u >> (g.sw + g.sh + g.sd));
+  } else {
+    long t = m;
+    x = (int)(t % g.gw);
+    t /= g.gw;
+    y = (int)(t % g.gh);
+    t /= g.gh;
+    z = (int)(t % g.gd);
+    b = (int)(t / g.gd);
+  }
+}
 
 constexpr int BM = 128, BK = 32, LDK = BK + 1, CT = 256;
 
@@ -112,13 +132,10 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
   for (int i = 0; i < 4; ++i) {
     const long m = m0 + r0 + 32 * i;
     rv[i] = m < g.M;
-    long t = rv[i] ? m : 0;
-    rx[i] = (int)(t % g.gw) * g.s;
-    t /= g.gw;
-    ry[i] = (int)(t % g.gh) * g.s;
-    t /= g.gh;
-    rz[i] = (int)(t % g.gd) * g.s;
-    rb[i] = (int)(t / g.gd);
+    grid_coords(g, rv[i] ? m : 0, rb[i], rz[i], ry[i], rx[i]);
+    rx[i] *= g.s;
+    ry[i] *= g.s;
+    rz[i] *= g.s;
   }
   const int ntaps = STEM ? 1 : class_ntaps(g, cls);
   const int KT = ntaps * g.kpt;
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
           const int z = rz[i] + a - 3, y = ry[i] + b - 3, x = rx[i] + c - 3;
           const bool ok = rv[i] && kk < 343 && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi &&
                           (unsigned)x < (unsigned)g.Wi;
-          v[j] = ok ? X[(((long)rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x] : 0.f;
+          v[j] = ok ? X[(unsigned)(((rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x)] : 0.f;
         }
         ra[i] = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
         const int z = rz[i] + dz, y = ry[i] + dy, x = rx[i] + dx;
         const bool ok = rv[i] && c0 < g.Cin && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi &&
                         (unsigned)x < (unsigned)g.Wi;
-        ra[i] = ok ? *(const float4*)(X + ((((long)rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x) * g.Cin + c0)
+        ra[i] = ok ? *(const float4*)(X + (long)(unsigned)(((rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x) * g.Cin + c0)
                    : make_float4(0, 0, 0, 0);
       }
 #pragma unroll
@@ -232,14 +249,9 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
       if (m >= g.M) continue;
       long orow = m;
       if (!dense_out) {
-        long t = m;
-        const int x = (int)(t % g.gw);
-        t /= g.gw;
-        const int y = (int)(t % g.gh);
-        t /= g.gh;
-        const int z = (int)(t % g.gd);
-        const int b = (int)(t / g.gd);
-        orow = (((long)b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw;
+        int b, z, y, x;
+        grid_coords(g, m, b, z, y, x);
+        orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
       }
 #pragma unroll
       for (int j = 0; j < C::TN; ++j) {
@@ -352,14 +364,9 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
 #pragma unroll
       for (int t = 0; t < NTAP; ++t) vx[t][h] = make_float4(0, 0, 0, 0);
       if (m < mend) {
-        long tt = m;
-        const int x = (int)(tt % g.gw);
-        tt /= g.gw;
-        const int y = (int)(tt % g.gh);
-        tt /= g.gh;
-        const int z = (int)(tt % g.gd);
-        const int b = (int)(tt / g.gd);
-        const long orow = (((long)b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw;
+        int b, z, y, x;
+        grid_coords(g, m, b, z, y, x);
+        const long orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
         const int n = n0 + sq * 4;
         if (n + 3 < g.Nout) {
           vy[h] = *(const float4*)(dY + orow * g.Nout + n);
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
             const int zz = z + a - 3, yy = y + bb - 3, xx = x + cc - 3;
             const bool ok = kk < 343 && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi &&
                             (unsigned)xx < (unsigned)g.Wi;
-            t4[e] = ok ? X[(((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx] : 0.f;
+            t4[e] = ok ? X[(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx)] : 0.f;
           }
           vx[0][h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         } else {
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
             const int zz = z * g.s + dz[t], yy = y * g.s + dy[t], xx = x * g.s + dx[t];
             if (tv[t] && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
                 c < g.Cin)
-              vx[t][h] = *(const float4*)(X + ((((long)b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
+              vx[t][h] = *(const float4*)(X + (long)(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
           }
         }
       }
@@ -598,6 +605,15 @@ struct ConvPlan {
   bool stem = false, dgrad_zero_fill = false;
 };
 
+static void set_shifts(IgemmGeom& g) {
+  g.sw = g.sh = g.sd = -1;
+  if (g.mode >= 0 && is_pow2(g.gw) && is_pow2(g.gh) && is_pow2(g.gd) && g.M < (1l << 32)) {
+    g.sw = ilog2(g.gw);
+    g.sh = ilog2(g.gh);
+    g.sd = ilog2(g.gd);
+  }
+}
+
 static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
   HP_REQUIRE(d.B >= 1 && d.Cin >= 1 && d.Cout >= 1, "conv: bad channel/batch sizes");
   const int k = d.k, s = d.stride, pad = d.pad;
@@ -658,6 +674,10 @@ static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
                         4, 2, 1, 0, (long)d.B * d.Di * d.Hi * d.Wi, d.Cout / 32};
     p.dgrad_classes = 1;
   }
+  HP_REQUIRE((long)d.B * d.Di * d.Hi * d.Wi * (d.transposed ? 8 : 1) < (1l << 31), "conv: more than 2^31 voxels per tensor");
+  set_shifts(p.fwd);
+  set_shifts(p.dgrad);
+  set_shifts(p.wgrad);
   return HP_OK;
 }
 
