@@ -141,6 +141,9 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
   const int KT = ntaps * g.kpt;
 
   float4 ra[4], rbw[BN / 32];
+  // running (tap, channel tile) of the NEXT tile to gather: no division in the K loop
+  int ld_tap = 0, ld_ci = 0, ld_dz = 0, ld_dy = 0, ld_dx = 0, ld_widx = 0;
+  if (!STEM) tap_info(g, cls, 0, ld_dz, ld_dy, ld_dx, ld_widx);
   auto load_tile = [&](int kt) {
     if constexpr (STEM) {
       // single input channel, 7^3 taps spread along K: element (row, kk) = x[voxel + off(kk)]
@@ -165,9 +168,8 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
         rbw[i] = n < g.Nout ? *(const float4*)(Wp + (long)n * (g.kpt * BK) + kbase) : make_float4(0, 0, 0, 0);
       }
     } else {
-      const int tap = kt / g.kpt, c0 = (kt - tap * g.kpt) * BK + kq * 4;
-      int dz, dy, dx, widx;
-      tap_info(g, cls, tap, dz, dy, dx, widx);
+      const int c0 = ld_ci * BK + kq * 4;
+      const int dz = ld_dz, dy = ld_dy, dx = ld_dx, widx = ld_widx;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int z = rz[i] + dz, y = ry[i] + dy, x = rx[i] + dx;
@@ -181,6 +183,10 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
         const int n = n0 + r0 + 32 * i;
         rbw[i] = (n < g.Nout && c0 < g.Cin) ? *(const float4*)(Wp + ((long)widx * g.Nout + n) * g.Cin + c0)
                                             : make_float4(0, 0, 0, 0);
+      }
+      if (++ld_ci == g.kpt) {
+        ld_ci = 0;
+        if (++ld_tap < ntaps) tap_info(g, cls, ld_tap, ld_dz, ld_dy, ld_dx, ld_widx);
       }
     }
   };
