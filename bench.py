@@ -236,6 +236,15 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches": n,
                         "avg_launch_us": round(1e3 * ms / n, 2),
                         "gflop_per_step": round(conv[name] / 1e9, 1)}
+                # HBM bytes of this kernel family per step from the committed PMC passes (rocprofv3 --pmc
+                # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH x2 on gfx950); only valid for the same workload
+                pmc = os.path.join(ROOT, "profiles", "round1_t512_pmc_hbm_traffic.json")
+                if args.workload == "t512" and B == 4 and os.path.exists(pmc):
+                    fam = json.load(open(pmc))
+                    key = name if name in fam else None
+                    if key:
+                        roof["traffic"] = fam[key]
+                        roof["traffic_unit"] = "GB of HBM per step over the family's launches (PMC, profiles/round1_t512_pmc_hbm_traffic.csv)"
             elif work and n:
                 bound, amount = work
                 avg_s = ms / n / 1e3
