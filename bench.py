@@ -261,7 +261,15 @@ def main():
                                              for k in sorted(cf) if k in prof and prof[k][1] > 0}
         line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            # the box's CPU share for one GPU is 16 cores: more threads than that only oversubscribe
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            threads = max(1, min(16, avail))
+            note(f"cpu_baseline: oracle train step on one 128^3 cube with {threads} threads ...")
+            line["cpu_baseline"] = cpu_baseline(threads)
+            note("cpu_baseline done")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
