@@ -125,17 +125,60 @@ def cpu_baseline(threads: int):
                       f"scaled x1/4; torch CPU fp32, {threads} threads"}
 
 
+def bench_sformer(args):
+    """BASELINE config 5: NlosPoseSformer (dim 256, depth 8, 8 heads x 32, patch 4, 16 frames of 128x128), batch 8,
+    forward only (the reference has no training loop for this head), fp32 MFMA attention."""
+    from hiddenpose_amd import _lib
+    from hiddenpose_amd.NlosPoseSformer import NlosPoseSformer
+
+    torch.cuda.set_device(0)
+    torch.manual_seed(410)
+    B = args.batch or 8
+    kw = dict(dim=256, num_frames=16, num_joints=24, image_size=128, patch_size=4, channels=1, depth=8, heads=8,
+              dim_head=32, out_dim=512)
+    model = NlosPoseSformer(**kw).cuda().eval()
+    video = torch.rand(B, 16, 1, 128, 128, device="cuda")
+    for _ in range(args.warmup):
+        model(video)
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model(video)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    ntok = 24 + 16 * 1024
+    attn_flops = 8 * (B * 8 * 16 * 1024 * (24 + 1024) * 32 * 4 + B * 8 * 24 * ntok * 32 * 4)
+    ms = prof.get("sformer_attention_patch", (0, 0.0))[1] + prof.get("sformer_attention_joint", (0, 0.0))[1]
+    ach = attn_flops * args.steps / (ms / 1e3) / 1e12 if ms else None
+    print(json.dumps({
+        "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"NlosPoseSformer forward, batch {B}, 16 frames x 128x128, patch 4, dim 256, depth 8, "
+                               "8 heads x 32, random-init weights"},
+        "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},
+        "roofline": {"kernel": "sformer_attention", "bound": "mfma", "achieved": round(ach, 2) if ach else None,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4) if ach else None,
+                     "traffic": None}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS) + ["sformer"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     args = ap.parse_args()
 
+    if args.workload == "sformer":
+        return bench_sformer(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

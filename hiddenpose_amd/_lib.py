@@ -72,6 +72,11 @@ SIGNATURES = {
     "hp_softargmax_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "hp_bce_dice_forward": (_i, [_fp, _fp, C.c_long, C.c_float, _vp, _fp, _vp]),
     "hp_bce_dice_backward": (_i, [_fp, _fp, _vp, _fp, _fp, C.c_long, C.c_float, _vp]),
+    "hp_sformer_patchify": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_layernorm_forward": (_i, [_fp, _fp, C.c_long, _i, _fp, _fp, C.c_float, _i, C.c_long, _vp]),
+    "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),
+    "hp_sformer_qkv_prepare": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_float, _fp, _fp, _i, _vp]),
+    "hp_sformer_attention": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 

@@ -71,6 +71,8 @@ def fill_module(module: torch.nn.Module, prefix: str = "", head_gain: float = 6.
     """Overwrite every tensor of module.state_dict() with fill_value(prefix+key)."""
     sd = module.state_dict()
     for key, t in sd.items():
+        if key.endswith((".scales", ".inv_freqs")):
+            continue  # rotary-embedding constants of the Sformer head stay as constructed
         v = fill_value(prefix + key, t.shape, head_gain)
         t.copy_(v.to(dtype=t.dtype, device=t.device))
 

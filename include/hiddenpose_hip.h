@@ -200,6 +200,31 @@ int hp_bce_dice_forward(const float* logit, const float* target, long n, float e
 int hp_bce_dice_backward(const float* logit, const float* target, const double* acc, const float* gloss, float* dlogit,
                          long n, float eps, void* stream);
 
+/* ------------------------------------------------------------------------
+ * NlosPoseSformer inference (models/NlosPoseSformer.py; BASELINE config 5).  Linear layers use
+ * hp_conv3d_forward with k = 1 (a 1x1x1 convolution over channels-last rows is a Linear; its packed
+ * weight layout equals the torch (out, in) layout).
+ * ---------------------------------------------------------------------- */
+/* rearrange 'b f c (h p1) (w p2) -> (b f h w) (p1 p2 c)'  (:104) */
+int hp_sformer_patchify(const float* video, float* tokens, int B, int frames, int C, int H, int W, int patch,
+                        void* stream);
+/* nn.LayerNorm over the last dim (:185-194, :76-79).  rows_per_batch > 0 selects rows
+ * (r / rows_per_batch) * batch_stride_rows + r % rows_per_batch of x (the joint tokens of every batch). */
+int hp_layernorm_forward(const float* x, float* y, long rows, int dim, const float* gamma, const float* beta, float eps,
+                         int rows_per_batch, long batch_stride_rows, void* stream);
+/* GEGLU (:197-201): g = u[:, :hidden] * gelu(u[:, hidden:]) with the exact (erf) GELU */
+int hp_geglu_forward(const float* u, float* g, long rows, int hidden, void* stream);
+/* chunk(3) + 'b n (h d) -> (b h) n d' + q * scale + axial RoPE on the patch tokens (:160-172, :298-313).
+ * K0 receives the keys WITHOUT the rotary embedding: the joint queries attend before it is applied (:305). */
+int hp_sformer_qkv_prepare(const float* qkv, float* Q, float* K, float* K0, float* V, int B, int Ntok, int heads, int dh,
+                           int num_joints, int patches_per_frame, float scale, const float* sin_t, const float* cos_t,
+                           int rot_dim, void* stream);
+/* spatial attention with joint tokens (:284-319): joint queries attend to all tokens, patch queries to
+ * [joint tokens | patches of their frame]; out (B, Ntok, heads*dh) with heads merged. */
+int hp_sformer_attention(const float* Q, const float* K, const float* K0, const float* V, float* out, int B, int heads,
+                         int dh, int Ntok,
+                         int num_joints, int patches_per_frame, int frames, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -287,6 +287,36 @@ def sec_softargmax():
     save("softargmax.npz", demo_pred=pred.numpy(), demo_loss=np.float64(loss.item()), rand_pred=rp.numpy())
 
 
+SFORMER_CFGS = {
+    "small": dict(dim=64, num_frames=4, num_joints=24, image_size=32, patch_size=8, channels=1, depth=2, heads=4,
+                  dim_head=16, out_dim=128),
+    "mid": dict(dim=128, num_frames=3, num_joints=24, image_size=64, patch_size=4, channels=1, depth=2, heads=4,
+                dim_head=32, out_dim=512),
+}
+
+
+def sec_sformer():
+    """NlosPoseSformer (models/NlosPoseSformer.py), the orphan RoPE transformer head of BASELINE config 5."""
+    import contextlib
+    import io
+
+    from models.NlosPoseSformer import NlosPoseSformer
+
+    out = {}
+    for tag, kw in SFORMER_CFGS.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = NlosPoseSformer(**kw)
+        hpt.fill_module(m, "sformer.")
+        m.eval()
+        g = torch.Generator().manual_seed(77)
+        video = torch.rand(2, kw["num_frames"], kw["channels"], kw["image_size"], kw["image_size"], generator=g)
+        with torch.no_grad():
+            y = m(video)
+        out[tag + "_y"] = y.numpy()
+        print(f"  sformer {tag}: out {tuple(y.shape)} std {y.std().item():.3g}")
+    save("sformer_io.npz", **out)
+
+
 def sec_schema():
     """state_dict key names and shapes of the reference NlosPose (checkpoint contract)."""
     import json
@@ -302,7 +332,7 @@ def sec_schema():
           f"{sum(int(np.prod(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k)} parameters")
 
 
-SECTIONS = {"schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
+SECTIONS = {"sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "softargmax": sec_softargmax}
 
 if __name__ == "__main__":

@@ -65,6 +65,10 @@ def install() -> None:
     tv.models = _stub("torchvision.models")
     tv.models.resnet = _stub("torchvision.models.resnet", BasicBlock=object, Bottleneck=object)
     _stub("mat73")
+    timm = _stub("timm")
+    timm.models = _stub("timm.models")
+    timm.models.layers = _stub("timm.models.layers")
+    timm.models.layers.weight_init = _stub("timm.models.layers.weight_init", trunc_normal_=torch.nn.init.trunc_normal_)
 
     # (2) legacy FFT names (torch<1.8) used by models/feature_propagation.py:228,235
     def rfft(x, signal_ndim, onesided=True):
