@@ -125,6 +125,7 @@ class NlosPoseSformer(nn.Module):
             k0 = torch.empty_like(q)
             v = torch.empty_like(q)
             att = torch.empty(b, ntok, inner, dtype=torch.float32, device=dev)
+            aws = torch.empty(int(L.hp_sformer_attention_workspace_bytes(b, heads, dh)) // 4, dtype=torch.float32, device=dev)
             for _time_attn, spatial, ff in self.layers:
                 a = spatial.fn
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, spatial.norm.weight.data_ptr(),
@@ -134,7 +135,7 @@ class NlosPoseSformer(nn.Module):
                                                     nj, n, a.scale, sin_t.data_ptr(), cos_t.data_ptr(), rot_dim, st),
                            "hp_sformer_qkv_prepare")
                 _lib.check(L.hp_sformer_attention(q.data_ptr(), k.data_ptr(), k0.data_ptr(), v.data_ptr(), att.data_ptr(), b, heads, dh, ntok, nj,
-                                                  n, f, st), "hp_sformer_attention")
+                                                  n, f, aws.data_ptr(), st), "hp_sformer_attention")
                 proj = _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias)
                 _lib.check(L.hp_leaky_add_forward(x.data_ptr(), proj.data_ptr(), x.data_ptr(), x.numel(), 1.0, st), "residual add")
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, ff.norm.weight.data_ptr(),

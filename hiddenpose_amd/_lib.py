@@ -76,7 +76,8 @@ SIGNATURES = {
     "hp_layernorm_forward": (_i, [_fp, _fp, C.c_long, _i, _fp, _fp, C.c_float, _i, C.c_long, _vp]),
     "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),
     "hp_sformer_qkv_prepare": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_float, _fp, _fp, _i, _vp]),
-    "hp_sformer_attention": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_sformer_attention_workspace_bytes": (_sz, [_i, _i, _i]),
+    "hp_sformer_attention": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 

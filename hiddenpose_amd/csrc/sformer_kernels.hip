@@ -121,7 +121,8 @@ __global__ __launch_bounds__(ST) void k_qkv_prepare(const float* __restrict__ qk
 template <int DH>
 __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V, float* __restrict__ out, int heads,
-                                                  int Ntok, int nj, int n, int frames, int mode) {
+                                                  int Ntok, int nj, int n, int frames, int mode,
+                                                  float* __restrict__ part) {
   constexpr int LD = DH + 1;
   __shared__ float Ks[4][32 * LD];
   __shared__ float Vs[4][32 * LD];
@@ -154,9 +155,14 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
   float m = -FLT_MAX, l = 0.f;
 
   const int ntiles = (nkeys + 31) / 32;
-  const int steps = mode == 0 ? ntiles : (ntiles + 3) / 4;
+  // joint mode: blockIdx.x is a key split; inside the split the tiles are dealt to the 4 waves
+  const int nsplit = mode == 0 ? 1 : (int)gridDim.x;
+  const int tiles_per_split = (ntiles + nsplit - 1) / nsplit;
+  const int tile0 = mode == 0 ? 0 : (int)blockIdx.x * tiles_per_split;
+  const int tile_end = mode == 0 ? ntiles : min(ntiles, tile0 + tiles_per_split);
+  const int steps = mode == 0 ? ntiles : (tiles_per_split + 3) / 4;
   for (int it = 0; it < steps; ++it) {
-    const int tile = mode == 0 ? it : it * 4 + wave;
+    const int tile = mode == 0 ? it : tile0 + it * 4 + wave;
     __syncthreads();
     if (mode == 0) {  // one tile for the whole block, staged by all 256 threads into region 0
       for (int i = tid; i < 32 * DH; i += ST) {
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
         const int kr = i / DH, d = i - kr * DH;
         const int kj = tile * 32 + kr;
         float kv = 0.f, vv = 0.f;
-        if (kj < nkeys) {
+        if (kj < nkeys && tile < tile_end) {
           kv = Kb[(long)kj * DH + d];
           vv = Vb[(long)kj * DH + d];
         }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
     __syncthreads();
     const float* ks = mode == 0 ? Ks[0] : Ks[wave];
     const float* vs = mode == 0 ? Vs[0] : Vs[wave];
-    if (tile >= ntiles) continue;  // (joint mode tail; barriers above stay uniform)
+    if (tile >= tile_end) continue;  // (joint mode tail; barriers above stay uniform)
     // S^T[key][query]
     f32x16 sacc;
 #pragma unroll
@@ -256,9 +262,10 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
       mrg_l[wave][col] = l;
     }
     __syncthreads();
+    // partial record of this split for every (query, d): unnormalised O, plus (max, sum) per query
+    float* rec = part + ((long)blockIdx.y * nsplit + blockIdx.x) * (32 * (DH + 2));
     for (int i = tid; i < 32 * DH; i += ST) {
       const int qr = i / DH, d = i - qr * DH;
-      if (qr >= nq) continue;
       float M = -FLT_MAX;
       for (int w = 0; w < 4; ++w) M = fmaxf(M, mrg_m[w][qr]);
       float Lsum = 0.f, o = 0.f;
@@ -267,9 +274,33 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
         Lsum += mrg_l[w][qr] * sc;
         o += Ks[w][qr * LD + d] * sc;
       }
-      out[((long)b * Ntok + qr) * inner + head * DH + d] = o / Lsum;
+      rec[qr * (DH + 2) + d] = o;
+      if (d == 0) {
+        rec[qr * (DH + 2) + DH] = M;
+        rec[qr * (DH + 2) + DH + 1] = Lsum;
+      }
     }
   }
+}
+
+// merge the key splits of the joint-token attention: one thread per (bh, query, d)
+__global__ void k_attention_joint_merge(const float* __restrict__ part, float* __restrict__ out, int BH, int heads, int dh,
+                                        int Ntok, int nq, int nsplit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BH * nq * dh) return;
+  const int d = i % dh, qr = (i / dh) % nq, bh = i / (dh * nq);
+  const int b = bh / heads, head = bh % heads;
+  const int rs = dh + 2;
+  float M = -FLT_MAX;
+  for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, part[((long)bh * nsplit + sp) * 32 * rs + qr * rs + dh]);
+  float L = 0.f, o = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float* rec = part + ((long)bh * nsplit + sp) * 32 * rs + qr * rs;
+    const float sc = rec[dh + 1] > 0.f ? __expf(rec[dh] - M) : 0.f;
+    L += rec[dh + 1] * sc;
+    o += rec[d] * sc;
+  }
+  out[((long)b * Ntok + qr) * heads * dh + head * dh + d] = o / L;
 }
 
 static unsigned sgrid(long n) { return (unsigned)std::max<long>(1, std::min<long>((n + ST - 1) / ST, 256 * 8)); }
@@ -323,26 +354,37 @@ extern "C" int hp_sformer_qkv_prepare(const float* qkv, float* Q, float* K, floa
   return HP_OK;
 }
 
+constexpr int JOINT_SPLITS = 32;
+extern "C" size_t hp_sformer_attention_workspace_bytes(int B, int heads, int dh) {
+  return sizeof(float) * (size_t)B * heads * JOINT_SPLITS * 32 * (dh + 2);
+}
+
 extern "C" int hp_sformer_attention(const float* Q, const float* K, const float* K0, const float* V, float* out, int B,
                                     int heads, int dh,
-                                    int Ntok, int num_joints, int patches_per_frame, int frames, void* stream) {
-  HP_REQUIRE(Q && K && K0 && V && out, "hp_sformer_attention: null argument");
+                                    int Ntok, int num_joints, int patches_per_frame, int frames, void* workspace, void* stream) {
+  HP_REQUIRE(Q && K && K0 && V && out && workspace, "hp_sformer_attention: null argument");
   HP_REQUIRE(num_joints <= 32 && Ntok == num_joints + frames * patches_per_frame, "hp_sformer_attention: bad token layout");
   if (dh != 16 && dh != 32) {
     set_error("hp_sformer_attention: dim_head %d not built (16, 32)", dh);
     return HP_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
-  const dim3 gp((patches_per_frame + 127) / 128, B * heads * frames), gj(1, B * heads);
+  const int ntiles = (Ntok + 31) / 32;
+  const int nsplit = std::max(1, std::min(JOINT_SPLITS, ntiles / 4));
+  float* part = (float*)workspace;
+  const dim3 gp((patches_per_frame + 127) / 128, B * heads * frames), gj(nsplit, B * heads);
   {
     HP_PROF("sformer_attention_patch", st);
-    if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0);
-    else hipLaunchKernelGGL((k_attention<16>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0);
+    if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
+    else hipLaunchKernelGGL((k_attention<16>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
   }
   {
     HP_PROF("sformer_attention_joint", st);
-    if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1);
-    else hipLaunchKernelGGL((k_attention<16>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1);
+    if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1, part);
+    else hipLaunchKernelGGL((k_attention<16>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1, part);
+    const int total = B * heads * num_joints * dh;
+    hipLaunchKernelGGL(k_attention_joint_merge, dim3((total + 255) / 256), dim3(256), 0, st, part, out, B * heads, heads, dh, Ntok,
+                       num_joints, nsplit);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

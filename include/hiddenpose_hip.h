@@ -221,9 +221,10 @@ int hp_sformer_qkv_prepare(const float* qkv, float* Q, float* K, float* K0, floa
                            int rot_dim, void* stream);
 /* spatial attention with joint tokens (:284-319): joint queries attend to all tokens, patch queries to
  * [joint tokens | patches of their frame]; out (B, Ntok, heads*dh) with heads merged. */
+size_t hp_sformer_attention_workspace_bytes(int B, int heads, int dh);
 int hp_sformer_attention(const float* Q, const float* K, const float* K0, const float* V, float* out, int B, int heads,
                          int dh, int Ntok,
-                         int num_joints, int patches_per_frame, int frames, void* stream);
+                         int num_joints, int patches_per_frame, int frames, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }
