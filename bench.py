@@ -166,12 +166,67 @@ def bench_sformer(args):
                      "traffic": None}}), flush=True)
 
 
+def bench_highres(args):
+    """BASELINE config 4: 256x256x1024 transient, FeatureExtraction -> LCT -> normalize -> UNet3d only
+    (forward + backward w.r.t. the FE / UNet parameters), batch 1, HBM-bandwidth roofline of the LCT."""
+    from hiddenpose_amd import _lib
+    from hiddenpose_amd import hip_ops as ops
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.feature_extraction import FeatureExtraction
+    from hiddenpose_amd.feature_propagation import FeaturePropagation
+    from hiddenpose_amd.unet3d import UNet3d
+
+    torch.cuda.set_device(0)
+    torch.manual_seed(410)
+    T, N, B = 1024, 256, args.batch or 1
+    t0 = time.perf_counter()
+    fe = FeatureExtraction(1, 1, stride=1).cuda()
+    fp = FeaturePropagation(image_size=N, time_size=T, bin_len=5.12 / T, wall_size=2.0).cuda()
+    un = UNet3d(1, 4).cuda()
+    meas = hpt.synthetic_meas(B, T, N).cuda()
+    fp.method.plan_for(meas.device)
+    print(f"[bench] constants + plan for T={T} N={N}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+
+    def step():
+        f = ops.normalize_feature(fp(fe(meas), [0] * B, [T] * B))
+        r = un(f)
+        (r.square().mean() + f.mean()).backward()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    V = T * N * N
+    lct_ms = sum(v[1] for k, v in prof.items() if k.startswith("lct_"))
+    lct_calls = 2 * args.steps  # forward + backward per step
+    ach = 40.0 * V * B * lct_calls / (lct_ms / 1e3) / 1e9 if lct_ms else None
+    print(json.dumps({
+        "metric": "samples/sec (256x256x1024 meas) FE+LCT+normalize+UNet fwd+bwd", "value": round(B * args.steps / dt, 3),
+        "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"FeatureExtraction+LCT+normalize_feature+UNet3d fwd+bwd, {N}x{N}x{T}, batch {B}"},
+        "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items()) if v[1] / args.steps > 0.05},
+        "roofline": {"kernel": "lct (5 passes, forward or adjoint)", "bound": "hbm", "achieved": round(ach, 1) if ach else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": None,
+                     "algorithmic_bytes": "40 * T*N*N per volume and direction (SURVEY 8d)",
+                     "ms_per_direction": round(lct_ms / lct_calls, 3) if lct_ms else None}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS) + ["sformer"])
+    ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS) + ["sformer", "highres"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
@@ -179,6 +234,8 @@ def main():
 
     if args.workload == "sformer":
         return bench_sformer(args)
+    if args.workload == "highres":
+        return bench_highres(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
