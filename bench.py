@@ -267,7 +267,12 @@ def main():
     model = NlosPose(cfg).to(dev)
     model.train()
     criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
-    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb) if world > 1 else None
+    force = bool(os.environ.get("HP_FORCE_REDUCER"))  # rehearse the DP code path on a single rank
+    if force and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, force_collectives=force) if (world > 1 or force) else None
 
     # synthetic batch of this rank (different samples per rank), resident in HBM before timing
     meas = hpt.synthetic_meas(B, T, N, "transient", seed=410 + rank * B).to(dev)

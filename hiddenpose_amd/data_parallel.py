@@ -23,12 +23,14 @@ import torch.distributed as dist
 
 class GradBucketReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, group: Optional[dist.ProcessGroup] = None,
-                 broadcast_from: int = 0):
+                 broadcast_from: int = 0, force_collectives: bool = False):
         self.module = module
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collectives: issue the (trivial) collectives even at world size 1, to rehearse the code path
+        self._active = self.world > 1 or (force_collectives and dist.is_initialized())
         params = [p for p in module.parameters() if p.requires_grad]
-        if self.world > 1:
+        if self._active:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=broadcast_from, group=group)
@@ -57,7 +59,7 @@ class GradBucketReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        if self._active:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.begin_step()
@@ -86,7 +88,7 @@ class GradBucketReducer:
     def finish(self) -> None:
         """Wait for every bucket (buckets whose parameters got no gradient this step are
         reduced here so that all ranks issue the same collectives)."""
-        if self.world > 1:
+        if self._active:
             for bi, left in enumerate(self._pending):
                 if left > 0:
                     self._pending[bi] = 0
