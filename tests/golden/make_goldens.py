@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: schema consts lct parts posenet e2e e2e128 softargmax   (default: all)
+Sections: sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax   (default: all)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
 its filler keyed by state_dict name, so tests rebuild identical inputs and
@@ -265,6 +265,11 @@ def sec_e2e128():
     save("e2e_T128_N128.npz", **_e2e(128, 128, 1, False))
 
 
+def sec_e2e512():
+    """The benchmark cube (BASELINE metric: 128x128x512), eval forward of the reference, batch 1."""
+    save("e2e_T512_N128.npz", **_e2e(512, 128, 1, False))
+
+
 def sec_softargmax():
     """The reference's own known-answer demo (utils/criterion.py:420-437): -1000
     background, +1 at one voxel per joint => decode returns that voxel, loss ~ 0."""
@@ -333,7 +338,7 @@ def sec_schema():
 
 
 SECTIONS = {"sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
-            "e2e": sec_e2e, "e2e128": sec_e2e128, "softargmax": sec_softargmax}
+            "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

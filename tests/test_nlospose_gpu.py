@@ -94,6 +94,24 @@ def test_eval_forward_native_128_vs_reference_golden(golden):
     assert abs(refine.double().norm().item() / float(g["eval_refine_l2"]) - 1) < TOL
 
 
+def test_eval_forward_bench_cube_512_vs_reference_golden(golden):
+    """The benchmark shape itself (128x128x512): joints, per-joint heat-map L2 and strided samples of the
+    reference's CPU forward."""
+    g = golden("e2e_T512_N128.npz")
+    cfg, model = make_model(512, 128)
+    meas = hpt.synthetic_meas(1, 512, 128).cuda()
+    model.eval()
+    with torch.no_grad():
+        heat, refine = model(meas)
+    assert heat.shape == (1, 24, 256, 64, 64)
+    joints = predict_joints(model, meas, cfg)
+    assert hpt.mpjpe(joints.cpu(), torch.from_numpy(g["eval_joints"])) < TOL * 64
+    l2 = heat.reshape(1, 24, -1).double().norm(dim=2).cpu().numpy()
+    assert np.abs(l2 / g["eval_heat_l2_per_joint"] - 1).max() < TOL
+    assert rel_l2(heat[:, :, ::8, ::8, ::8], g["eval_heat_sub"]) < TOL
+    assert rel_l2(refine[:, :, ::8, ::8, ::8], g["eval_refine_sub"]) < TOL
+
+
 def test_softargmax_known_answer_on_device(golden):
     g = golden("softargmax.npz")
     inp = torch.zeros(1, 24, 5, 5, 5) - 1000
