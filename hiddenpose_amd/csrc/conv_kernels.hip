@@ -112,7 +112,8 @@ struct TileCfg {
 template <int BN, bool STEM, bool STATS>
 __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, float* __restrict__ Y,
-                                              double* __restrict__ stats, IgemmGeom g) {
+                                              double* __restrict__ stats, const float* __restrict__ addend,
+                                              IgemmGeom g) {
   using C = TileCfg<BN>;
   __shared__ float As[BM * LDK];
   __shared__ float Bs[BN * LDK];
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
 #pragma unroll
       for (int j = 0; j < C::TN; ++j) {
         const int n = n0 + wn * C::TN * 32 + j * 32 + (lane & 31);
-        if (n < g.Nout) Y[orow * g.Nout + n] = acc[i][j][r] + (bias ? bias[n] : 0.f);
+        if (n < g.Nout)
+          Y[orow * g.Nout + n] = acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? addend[orow * g.Nout + n] : 0.f);
       }
     }
   }
@@ -689,26 +691,26 @@ static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
 
 template <bool STEM, bool STATS>
 static void launch_igemm_bn(const IgemmGeom& g, int classes, const float* X, const float* W, const float* bias, float* Y,
-                            double* stats, hipStream_t st) {
+                            double* stats, const float* addend, hipStream_t st) {
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (g.Nout > 64) {
     hipLaunchKernelGGL((k_igemm<128, STEM, STATS>), dim3(mt, (g.Nout + 127) / 128, classes), dim3(CT), 0, st, X, W,
-                       bias, Y, stats, g);
+                       bias, Y, stats, addend, g);
   } else if (g.Nout > 32) {
-    hipLaunchKernelGGL((k_igemm<64, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, g);
+    hipLaunchKernelGGL((k_igemm<64, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
   } else {
-    hipLaunchKernelGGL((k_igemm<32, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, g);
+    hipLaunchKernelGGL((k_igemm<32, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
   }
 }
 
 static void launch_igemm(const IgemmGeom& g, int classes, bool stem, const float* X, const float* W, const float* bias,
-                         float* Y, double* stats, hipStream_t st) {
+                         float* Y, double* stats, const float* addend, hipStream_t st) {
   if (stem) {
-    if (stats) launch_igemm_bn<true, true>(g, classes, X, W, bias, Y, stats, st);
-    else launch_igemm_bn<true, false>(g, classes, X, W, bias, Y, stats, st);
+    if (stats) launch_igemm_bn<true, true>(g, classes, X, W, bias, Y, stats, addend, st);
+    else launch_igemm_bn<true, false>(g, classes, X, W, bias, Y, stats, addend, st);
   } else {
-    if (stats) launch_igemm_bn<false, true>(g, classes, X, W, bias, Y, stats, st);
-    else launch_igemm_bn<false, false>(g, classes, X, W, bias, Y, stats, st);
+    if (stats) launch_igemm_bn<false, true>(g, classes, X, W, bias, Y, stats, addend, st);
+    else launch_igemm_bn<false, false>(g, classes, X, W, bias, Y, stats, addend, st);
   }
 }
 
@@ -778,14 +780,14 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
   {
     HP_PROF(p.stem ? "conv_igemm_stem" : d->transposed ? "conv_igemm_deconv" : d->k == 1 ? "conv_igemm_k1" : "conv_igemm_k3", st);
-    launch_igemm(p.fwd, p.fwd_classes, p.stem, x, w_fwd, bias, y, stats, st);
+    launch_igemm(p.fwd, p.fwd_classes, p.stem, x, w_fwd, bias, y, stats, nullptr, st);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
 
 extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                       void* stream) {
+                                       const float* addend, void* stream) {
   HP_REQUIRE(d && dy && w_dgrad && dx, "hp_conv3d_backward_data: null argument");
   ConvPlan p;
   int rc = make_plan(*d, p);
@@ -793,7 +795,9 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
   hipStream_t st = (hipStream_t)stream;
   if (p.stem) {
     HP_REQUIRE(d->Cout == 64, "stem data gradient: 64 output channels expected (got %d)", d->Cout);
-    HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi, st));
+    const size_t nb = sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi;
+    if (addend) HP_CHECK_HIP(hipMemcpyAsync(dx, addend, nb, hipMemcpyDeviceToDevice, st));
+    else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     HP_PROF("conv_stem_dgrad", st);
     hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, dy, w_dgrad, dx,
@@ -801,11 +805,14 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
-  if (p.dgrad_zero_fill)
-    HP_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin, st));
+  if (p.dgrad_zero_fill) {  // strided 1^3 convolution: only every second voxel per axis receives a contribution
+    const size_t nb = sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin;
+    if (addend) HP_CHECK_HIP(hipMemcpyAsync(dx, addend, nb, hipMemcpyDeviceToDevice, st));
+    else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
+  }
   {
     HP_PROF("conv_igemm_dgrad", st);
-    launch_igemm(p.dgrad, p.dgrad_classes, false, dy, w_dgrad, nullptr, dx, nullptr, st);
+    launch_igemm(p.dgrad, p.dgrad_classes, false, dy, w_dgrad, nullptr, dx, nullptr, addend, st);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

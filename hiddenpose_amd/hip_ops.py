@@ -337,7 +337,19 @@ def _pack(desc, w, want_fwd, want_dgrad):
     return wf, wd
 
 
-def _conv_grads(desc, x, w, dz, need_dx):
+class GradLink:
+    """Carries one gradient contribution to a tensor that is used twice inside a Bottleneck (block input:
+    conv1 + identity shortcut, or conv1 + shortcut convolution) from the autograd node that produces it
+    first to the data-gradient GEMM that runs last, which adds it in its epilogue.  Replaces the
+    separate accumulation pass autograd would issue."""
+    __slots__ = ("g", "arrivals")
+
+    def __init__(self):
+        self.g = None
+        self.arrivals = 0
+
+
+def _conv_grads(desc, x, w, dz, need_dx, addend=None):
     """(dx, dw) of z = conv(x, w) given dz; all channels-last, dw in the torch weight layout."""
     L = _lib.lib()
     st = _stream(x)
@@ -345,7 +357,7 @@ def _conv_grads(desc, x, w, dz, need_dx):
     if need_dx:
         _, wd = _pack(desc, w, False, True)
         dx = torch.empty_like(x)
-        _lib.check(L.hp_conv3d_backward_data(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), st),
+        _lib.check(L.hp_conv3d_backward_data(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend), st),
                    "hp_conv3d_backward_data")
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
     dwp = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -360,7 +372,7 @@ class _ConvBnAct(torch.autograd.Function):
     """y = act(BN(conv(x)) [+ res]) with the BN batch statistics reduced in the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu):
+    def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None):
         L = _lib.lib()
         x = x.contiguous()
         cout = w.shape[1] if transposed else w.shape[0]
@@ -393,6 +405,7 @@ class _ConvBnAct(torch.autograd.Function):
                                      gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, st), "hp_bn_apply")
         ctx.save_for_backward(x, w, gamma, z, y, mean, rstd)
         ctx.cfg = (desc, relu, train, res is not None)
+        ctx.links = (link_in, link_out)
         return y
 
     @staticmethod
@@ -414,8 +427,20 @@ class _ConvBnAct(torch.autograd.Function):
                                         mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), 1 if relu else 0,
                                         1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), st),
                        "hp_bn_backward")
-            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0])
-        return dx, dw, dgamma, dbeta, g, None, None, None, None, None, None
+            link_in, link_out = ctx.links
+            addend = None
+            last = True
+            if link_in is not None and ctx.needs_input_grad[0]:
+                link_in.arrivals -= 1
+                addend, link_in.g = link_in.g, None
+                last = link_in.arrivals == 0
+            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend)
+            if not last:           # first of two convolutions reading the block input: park the partial sum
+                link_in.g, dx = dx, None
+            gres = g
+            if link_out is not None and has_res:   # identity shortcut: hand g to the block's conv1 data gradient
+                link_out.g, gres = g, None
+        return dx, dw, dgamma, dbeta, gres, None, None, None, None, None, None, None, None
 
 
 class _ConvBiasToNCDHW(torch.autograd.Function):
@@ -482,10 +507,10 @@ class _MaxPool3CL(torch.autograd.Function):
         return dx
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None):
     """x channels-last (B,D,H,W,C)."""
     return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.kernel_size[0], conv.stride[0],
-                            conv.padding[0], False, relu)
+                            conv.padding[0], False, relu, link_in, link_out)
 
 
 def deconv_bn_relu(x, deconv, bn):

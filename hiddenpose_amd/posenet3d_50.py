@@ -33,13 +33,19 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        # The block input feeds two consumers; their gradients are summed inside the data-gradient GEMM that
+        # finishes last (hip_ops.GradLink) instead of by a separate accumulation pass.
+        link = ops.GradLink() if (torch.is_grad_enabled() and x.requires_grad) else None
+        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link)
         o = ops.conv_bn_act(o, self.conv2, self.bn2, relu=True)
         if self.downsample is not None:
-            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        else:
-            res = x
-        return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res)
+            if link is not None:
+                link.arrivals = 2      # conv1 and the shortcut convolution both produce d(block input)
+            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link)
+            return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res)
+        if link is not None:
+            link.arrivals = 1          # conv1 adds the identity-shortcut gradient parked by conv3's node
+        return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=x, link_out=link)
 
 
 class DeconvHead(nn.Module):

@@ -108,7 +108,10 @@ int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_packed, float*
  * (2*Cout doubles, zeroed by the call) for train-mode BatchNorm. */
 int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd, const float* bias, float* y,
                       double* stats, void* stream);
-int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx, void* stream);
+/* dx = conv^T(dy) [+ addend]: `addend` (same shape as dx, may be NULL) lets a second gradient contribution to the
+ * same tensor (residual / shortcut branch) be summed in the epilogue instead of by a separate pass. */
+int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                            const float* addend, void* stream);
 /* dw_packed (same layout as w_fwd) is zeroed and accumulated by the call. */
 int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float* dy, float* dw_packed, void* stream);
 
