@@ -224,18 +224,28 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
   for (int kt = -1; kt < KT; ++kt) {
     if (kt + 1 < KT) load_tile(kt + 1);
     if (kt >= 0) {
+      // fragments of step kk+1 are fetched from LDS while the MFMAs of step kk run (two register sets)
+      float fa[2][C::TM], fb[2][C::TN];
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i) fa[0][i] = ap[i * 32 * LDK];
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) fb[0][j] = bp[j * 32 * LDK];
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
-        float a[C::TM], b[C::TN];
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i) a[i] = ap[i * 32 * LDK + 2 * kk];
+          for (int i = 0; i < C::TM; ++i) fa[nxt][i] = ap[i * 32 * LDK + 2 * (kk + 1)];
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j) b[j] = bp[j * 32 * LDK + 2 * kk];
+          for (int j = 0; j < C::TN; ++j) fb[nxt][j] = bp[j * 32 * LDK + 2 * (kk + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
           for (int j = 0; j < C::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
@@ -319,7 +329,8 @@ constexpr int WG_KM = 32;  // voxels per step
 // NTAP gathered X tiles (1 + NTAP LDS fragment reads feed NTAP MFMAs).
 template <bool STEM, int TT, int NTAP>
 __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
-                                              float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit) {
+                                              float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit,
+                                              int tiles_total, int tap_groups) {
   constexpr int QN = TT / 4;            // float4 per staged row
   constexpr int RPP = CT / QN;          // rows per staging pass
   constexpr int RPT = WG_KM / RPP;      // rows per thread
@@ -328,9 +339,14 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
   __shared__ float Ys[WG_KM * TT];
   __shared__ float Xs[NTAP * WG_KM * TT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile_n = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  // 1-D grid, tap group fastest: blocks that run together share the same voxel range, so the dY rows and
+  // the (shifted) X rows they gather are served by L2 / Infinity Cache instead of being re-fetched per tap
+  const int bid_tap = blockIdx.x % tap_groups;
+  const int bid_tile = (blockIdx.x / tap_groups) % tiles_total;
+  const int bid_split = blockIdx.x / (tap_groups * tiles_total);
+  const int tile_n = bid_tile / tiles_c, tile_c = bid_tile % tiles_c;
   const int n0 = tile_n * TT, c0 = tile_c * TT;
-  int cls = 0, tap = blockIdx.y * NTAP;  // blockIdx.y enumerates (class, tap group)
+  int cls = 0, tap = bid_tap * NTAP;  // (class, tap group)
   if (!STEM && NTAP == 1) {
     while (tap >= class_ntaps(g, cls)) {
       tap -= class_ntaps(g, cls);
@@ -348,7 +364,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
     if (!STEM && tv[t]) tap_info(g, cls, tap + t, dz[t], dy[t], dx[t], widx[t]);
   }
   const long chunk = ((g.M + msplit - 1) / msplit + WG_KM - 1) / WG_KM * WG_KM;
-  const long mbeg = (long)blockIdx.z * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
+  const long mbeg = (long)bid_split * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
   const int Kc = STEM ? g.kpt * BK : g.Cin;  // extent of the c axis
   const int sq = tid % QN, sr = tid / QN;
   const int wn = wave >> 1, wc = wave & 1;
@@ -421,23 +437,31 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
     }
     __syncthreads();
     if (mb + WG_KM < mend) load_step(mb + WG_KM);
-#pragma unroll
-    for (int kk = 0; kk < WG_KM / 2; ++kk) {
+    // two fragment register sets: step kk+1 is read from LDS while the MFMAs of step kk run
+    float fa[2][WT], fb[2][NTAP][WT];
+    auto frag = [&](int set, int kk) {
       const int mrow = 2 * kk + (lane >> 5);
-      float a[WT], b[NTAP][WT];
 #pragma unroll
-      for (int i = 0; i < WT; ++i) a[i] = Ys[mrow * TT + wn * (TT / 2) + i * 32 + (lane & 31)];
+      for (int i = 0; i < WT; ++i) fa[set][i] = Ys[mrow * TT + wn * (TT / 2) + i * 32 + (lane & 31)];
 #pragma unroll
       for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) b[t][j] = Xs[(t * WG_KM + mrow) * TT + wc * (TT / 2) + j * 32 + (lane & 31)];
+        for (int j = 0; j < WT; ++j) fb[set][t][j] = Xs[(t * WG_KM + mrow) * TT + wc * (TT / 2) + j * 32 + (lane & 31)];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < WG_KM / 2; ++kk) {
+      const int cur = kk & 1;
+      if (kk + 1 < WG_KM / 2) frag(cur ^ 1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
       for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int i = 0; i < WT; ++i)
 #pragma unroll
           for (int j = 0; j < WT; ++j)
-            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][t][j], acc[t][i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // dW layout: [slab][n][Kc]
@@ -834,16 +858,17 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
   const int tap_groups = multitap ? (27 + 3) / 4 : p.wgrad_tapsum;
   const int tiles_n = (g.Nout + TT - 1) / TT, tiles_c = (Kc + TT - 1) / TT;
   const long base_blocks = (long)tiles_n * tiles_c * tap_groups;
-  long msplit = std::max<long>(1, (1536 + base_blocks - 1) / base_blocks);
+  long msplit = std::max<long>(1, (4096 + base_blocks - 1) / base_blocks);
   msplit = std::min<long>(msplit, std::max<long>(1, g.M / (4 * WG_KM)));
   msplit = std::min<long>(msplit, 4096);
-  dim3 grid((unsigned)(tiles_n * tiles_c), (unsigned)tap_groups, (unsigned)msplit);
+  const int tiles_total = tiles_n * tiles_c;
+  dim3 grid((unsigned)((long)tiles_total * tap_groups * msplit));
   {
     HP_PROF("conv_wgrad", st);
-    if (p.stem) hipLaunchKernelGGL((k_wgrad<true, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
-    else if (TT == 128) hipLaunchKernelGGL((k_wgrad<false, 128, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
-    else if (multitap) hipLaunchKernelGGL((k_wgrad<false, 64, 4>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
-    else hipLaunchKernelGGL((k_wgrad<false, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit);
+    if (p.stem) hipLaunchKernelGGL((k_wgrad<true, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+    else if (TT == 128) hipLaunchKernelGGL((k_wgrad<false, 128, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+    else if (multitap) hipLaunchKernelGGL((k_wgrad<false, 64, 4>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+    else hipLaunchKernelGGL((k_wgrad<false, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
