@@ -115,8 +115,10 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
                                               double* __restrict__ stats, const float* __restrict__ addend,
                                               IgemmGeom g) {
   using C = TileCfg<BN>;
-  __shared__ float As[BM * LDK];
-  __shared__ float Bs[BN * LDK];
+  // one LDS arena: A and B tiles during the K loop, then the output staging tile of the epilogue
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  float* const As = smem;
+  float* const Bs = smem + BM * LDK;
   __shared__ float red[STATS ? 2 * BN * C::WM : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
@@ -257,24 +259,77 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
 
   // ---- epilogue
   const bool dense_out = (g.os == 1 && g.gd == g.Do && g.gh == g.Ho && g.gw == g.Wo);
+  if constexpr (BN >= 64) {
+    // The accumulators leave through LDS so that every lane moves 16 contiguous bytes of one output row
+    // (bias / shortcut-gradient addend are read the same way); 64 tile rows per round.
+    constexpr int LDO = BN + 4, Q = BN / 4;
+    static_assert(64 * LDO <= (BM + BN) * LDK, "staging tile must fit the arena");
+    static_assert(C::WM == 2 && C::TM == 2, "epilogue assumes 2 waves x 2 MFMA tiles along M");
+    const bool vec_ok = (g.Nout & 3) == 0;
 #pragma unroll
-  for (int i = 0; i < C::TM; ++i) {
+    for (int h = 0; h < C::TM; ++h) {
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const long m = m0 + row;
-      if (m >= g.M) continue;
-      long orow = m;
-      if (!dense_out) {
-        int b, z, y, x;
-        grid_coords(g, m, b, z, y, x);
-        orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) smem[rl * LDO + wn * C::TN * 32 + j * 32 + (lane & 31)] = acc[h][j][r];
       }
+      __syncthreads();
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + wn * C::TN * 32 + j * 32 + (lane & 31);
-        if (n < g.Nout)
-          Y[orow * g.Nout + n] = acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? addend[orow * g.Nout + n] : 0.f);
+      for (int k2 = 0; k2 < (64 * Q) / CT; ++k2) {
+        const int idx = tid + k2 * CT;
+        const int row64 = idx / Q, q = idx - row64 * Q;
+        const int trow = (row64 >> 5) * (C::TM * 32) + h * 32 + (row64 & 31);
+        const long m = m0 + trow;
+        const int n = n0 + 4 * q;
+        if (m >= g.M || n >= g.Nout) continue;
+        long orow = m;
+        if (!dense_out) {
+          int b, z, y, x;
+          grid_coords(g, m, b, z, y, x);
+          orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
+        }
+        float4 v = *(const float4*)(smem + row64 * LDO + 4 * q);
+        float* yp = Y + orow * g.Nout + n;
+        if (vec_ok) {
+          if (bias) {
+            const float4 bv = *(const float4*)(bias + n);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (addend) {
+            const float4 av = *(const float4*)(addend + orow * g.Nout + n);
+            v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
+          }
+          *(float4*)yp = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4; ++e)
+            if (n + e < g.Nout)
+              yp[e] = vv[e] + (bias ? bias[n + e] : 0.f) + (addend ? addend[orow * g.Nout + n + e] : 0.f);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * C::TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long m = m0 + row;
+        if (m >= g.M) continue;
+        long orow = m;
+        if (!dense_out) {
+          int b, z, y, x;
+          grid_coords(g, m, b, z, y, x);
+          orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
+        }
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+          const int n = n0 + wn * C::TN * 32 + j * 32 + (lane & 31);
+          if (n < g.Nout)
+            Y[orow * g.Nout + n] = acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? addend[orow * g.Nout + n] : 0.f);
+        }
       }
     }
   }
