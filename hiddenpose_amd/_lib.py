@@ -50,6 +50,9 @@ SIGNATURES = {
     "hp_maxpool3d_k3s2_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "hp_maxpool3d_k3s2_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "hp_layout_transpose": (_i, [_fp, _fp, _i, C.c_long, _i, _i, _vp]),
+    "hp_stem_bn_pool_workspace_bytes": (_sz, [_i]),
+    "hp_stem_bn_relu_pool_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "hp_stem_bn_relu_pool_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _fp, _fp, _vp, _vp]),
     "hp_dconv3_forward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hp_dconv3_backward_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "hp_dconv3_backward_data": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

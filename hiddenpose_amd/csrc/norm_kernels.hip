@@ -4,6 +4,7 @@
 // All of them stream 16 bytes per lane; per-channel reductions go through LDS and end in
 // one fp64 atomic per channel per block.
 #include <algorithm>
+#include <cstdint>
 
 #include "hp_internal.h"
 
@@ -248,6 +249,164 @@ __global__ __launch_bounds__(ET) void k_maxpool3_bwd(const float4* __restrict__ 
   }
 }
 
+// ---- stem: BatchNorm + ReLU + MaxPool3d(3,2,1) without materialising the normalised 64-channel volume.
+// y = relu(z * sc + sh) with sc = rstd * gamma, sh = beta - mean * sc  (recomputed wherever it is needed)
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
+  return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
+                     fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+}
+
+__global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restrict__ z, float4* __restrict__ p, int B, int D,
+                                                          int H, int W, int C4, const float4* __restrict__ sc,
+                                                          const float4* __restrict__ sh) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * Do * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    t /= Ho;
+    const int od = (int)(t % Do);
+    const int b = (int)(t / Do);
+    const float4 a = sc[c], s0 = sh[c];
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // ReLU output is >= 0 and every window holds a valid voxel
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = 2 * od + dz;
+      if ((unsigned)zz >= (unsigned)D) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = 2 * oh + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = 2 * ow + dx;
+          if ((unsigned)xx >= (unsigned)W) continue;
+          const float4 v = bn_relu4(z[((((long)b * D + zz) * H + yy) * W + xx) * C4 + c], a, s0);
+          m.x = fmaxf(m.x, v.x);
+          m.y = fmaxf(m.y, v.y);
+          m.z = fmaxf(m.z, v.z);
+          m.w = fmaxf(m.w, v.w);
+        }
+      }
+    }
+    p[i] = m;
+  }
+}
+
+// g[i] = [y_i > 0] * sum over the <= 8 windows o containing i of dp[o] * [y_i == p[o]]   (y recomputed from z)
+__device__ __forceinline__ float4 stem_pool_grad(const float4* __restrict__ p, const float4* __restrict__ dp, float4 y,
+                                                 int b, int d, int h, int w, int c, int D, int H, int W, int C4) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  float4 acc = make_float4(0, 0, 0, 0);
+  const int d0 = d / 2, d1 = (d + 1) / 2, h0 = h / 2, h1 = (h + 1) / 2, w0 = w / 2, w1 = (w + 1) / 2;
+  for (int a = 0; a < 2; ++a) {
+    const int od = a ? d1 : d0;
+    if ((a && d1 == d0) || od >= Do) continue;
+    for (int bb = 0; bb < 2; ++bb) {
+      const int oh = bb ? h1 : h0;
+      if ((bb && h1 == h0) || oh >= Ho) continue;
+      for (int cc = 0; cc < 2; ++cc) {
+        const int ow = cc ? w1 : w0;
+        if ((cc && w1 == w0) || ow >= Wo) continue;
+        const long o = ((((long)b * Do + od) * Ho + oh) * Wo + ow) * C4 + c;
+        const float4 m = p[o], gg = dp[o];
+        acc.x += (y.x == m.x) ? gg.x : 0.f;
+        acc.y += (y.y == m.y) ? gg.y : 0.f;
+        acc.z += (y.z == m.z) ? gg.z : 0.f;
+        acc.w += (y.w == m.w) ? gg.w : 0.f;
+      }
+    }
+  }
+  acc.x = y.x > 0.f ? acc.x : 0.f;
+  acc.y = y.y > 0.f ? acc.y : 0.f;
+  acc.z = y.z > 0.f ? acc.z : 0.f;
+  acc.w = y.w > 0.f ? acc.w : 0.f;
+  return acc;
+}
+
+// pass 1: per channel sum(g), sum(g * zhat) -> red[0:C], red[C:2C].  Requires 4*C4 <= ET... thread t owns channel
+// quad t % C4 and strides over voxels, so per-thread sums stay per channel (C4 = 16 for the 64-channel stem).
+__global__ __launch_bounds__(ET) void k_stem_bwd_reduce(const float4* __restrict__ z, const float4* __restrict__ p,
+                                                        const float4* __restrict__ dp, int B, int D, int H, int W, int C4,
+                                                        const float4* __restrict__ sc, const float4* __restrict__ sh,
+                                                        const float4* __restrict__ mean, const float4* __restrict__ rstd,
+                                                        double* __restrict__ red) {
+  __shared__ float4 ssum[ET], sdot[ET];
+  const int tid = threadIdx.x;
+  const int cq = tid % C4, vrow = tid / C4, vpb = ET / C4;
+  const long nvox = (long)B * D * H * W;
+  const float4 a = sc[cq], s0 = sh[cq], mu = mean[cq], rs = rstd[cq];
+  float4 s = make_float4(0, 0, 0, 0), dd = make_float4(0, 0, 0, 0);
+  for (long v = (long)blockIdx.x * vpb + vrow; v < nvox; v += (long)gridDim.x * vpb) {
+    long t = v;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    const float4 zv = z[v * C4 + cq];
+    const float4 g = stem_pool_grad(p, dp, bn_relu4(zv, a, s0), b, d, h, w, cq, D, H, W, C4);
+    s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+    dd.x += g.x * (zv.x - mu.x) * rs.x;
+    dd.y += g.y * (zv.y - mu.y) * rs.y;
+    dd.z += g.z * (zv.z - mu.z) * rs.z;
+    dd.w += g.w * (zv.w - mu.w) * rs.w;
+  }
+  ssum[tid] = s;
+  sdot[tid] = dd;
+  __syncthreads();
+  if (vrow == 0) {
+    for (int rr = 1; rr < vpb; ++rr) {
+      const float4 x1 = ssum[rr * C4 + cq], x2 = sdot[rr * C4 + cq];
+      s.x += x1.x; s.y += x1.y; s.z += x1.z; s.w += x1.w;
+      dd.x += x2.x; dd.y += x2.y; dd.z += x2.z; dd.w += x2.w;
+    }
+    const int C = C4 * 4;
+    atomicAdd(red + cq * 4 + 0, (double)s.x);
+    atomicAdd(red + cq * 4 + 1, (double)s.y);
+    atomicAdd(red + cq * 4 + 2, (double)s.z);
+    atomicAdd(red + cq * 4 + 3, (double)s.w);
+    atomicAdd(red + C + cq * 4 + 0, (double)dd.x);
+    atomicAdd(red + C + cq * 4 + 1, (double)dd.y);
+    atomicAdd(red + C + cq * 4 + 2, (double)dd.z);
+    atomicAdd(red + C + cq * 4 + 3, (double)dd.w);
+  }
+}
+
+// pass 2: dz = ca * g + cb * z + cc with g recomputed
+__global__ __launch_bounds__(ET) void k_stem_bwd_apply(const float4* __restrict__ z, const float4* __restrict__ p,
+                                                       const float4* __restrict__ dp, float4* __restrict__ dz, int B, int D,
+                                                       int H, int W, int C4, const float4* __restrict__ sc,
+                                                       const float4* __restrict__ sh, const float4* __restrict__ ca,
+                                                       const float4* __restrict__ cb, const float4* __restrict__ cc) {
+  const long total = (long)B * D * H * W * C4;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int d = (int)(t % D);
+    const int b = (int)(t / D);
+    const float4 zv = z[i];
+    const float4 g = stem_pool_grad(p, dp, bn_relu4(zv, sc[c], sh[c]), b, d, h, w, c, D, H, W, C4);
+    const float4 a = ca[c], bq = cb[c], k = cc[c];
+    dz[i] = make_float4(fmaf(a.x, g.x, fmaf(bq.x, zv.x, k.x)), fmaf(a.y, g.y, fmaf(bq.y, zv.y, k.y)),
+                        fmaf(a.z, g.z, fmaf(bq.z, zv.z, k.z)), fmaf(a.w, g.w, fmaf(bq.w, zv.w, k.w)));
+  }
+}
+
+__global__ void k_bn_scale_shift(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, int C, float* __restrict__ sc, float* __restrict__ sh) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float a = rstd[c] * gamma[c];
+  sc[c] = a;
+  sh[c] = beta[c] - mean[c] * a;
+}
+
 // [B][V][C] <-> [B][C][V] through a 32x32 LDS tile
 __global__ void k_transpose_vc(const float* __restrict__ in, float* __restrict__ out, long V, int C, int to_ncv) {
   __shared__ float t[32][33];
@@ -389,6 +548,63 @@ extern "C" int hp_layout_transpose(const float* in, float* out, int B, long V, i
   HP_PROF("layout_transpose", st);
   hipLaunchKernelGGL(k_transpose_vc, dim3((unsigned)((V + 31) / 32), (C + 31) / 32, B), dim3(256), 0, st, in, out, V, C,
                      to_channels_first);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// ---- stem: fused BatchNorm + ReLU + MaxPool3d(3,2,1) (posenet3d_50.py:253-257); z channels-last (B,D,H,W,C)
+// workspace (floats): 2*C scale/shift | 3*C coefficients | then 2*C doubles for the reduction
+extern "C" size_t hp_stem_bn_pool_workspace_bytes(int C) { return sizeof(float) * 5 * C + sizeof(double) * 2 * C + 16; }
+
+extern "C" int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B, int D, int H, int W, int C, const float* mean,
+                                            const float* rstd, const float* gamma, const float* beta, void* workspace,
+                                            void* stream) {
+  HP_REQUIRE(z && pooled && mean && rstd && gamma && beta && workspace && C % 4 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
+             "hp_stem_bn_relu_pool_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* sc = (float*)workspace;
+  float* sh = sc + C;
+  hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 127) / 128), dim3(128), 0, st, mean, rstd, gamma, beta, C, sc, sh);
+  HP_PROF("stem_bn_relu_pool_fwd", st);
+  const long n = (long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(k_bn_relu_pool3_fwd, dim3(grid_for(n)), dim3(ET), 0, st, (const float4*)z, (float4*)pooled, B, D, H, W, C / 4,
+                     (const float4*)sc, (const float4*)sh);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled, const float* dpooled, float* dz, int B, int D,
+                                             int H, int W, int C, const float* mean, const float* rstd, const float* gamma,
+                                             const float* beta, int train, float* dgamma, float* dbeta, void* workspace,
+                                             void* stream) {
+  HP_REQUIRE(z && pooled && dpooled && dz && mean && rstd && gamma && beta && workspace && C % 4 == 0 && (ET % (C / 4)) == 0,
+             "hp_stem_bn_relu_pool_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* sc = (float*)workspace;
+  float* sh = sc + C;
+  float* ca = sh + C;
+  float* cb = ca + C;
+  float* cc = cb + C;
+  double* red = (double*)(((uintptr_t)(cc + C) + 15) & ~(uintptr_t)15);
+  hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 127) / 128), dim3(128), 0, st, mean, rstd, gamma, beta, C, sc, sh);
+  HP_CHECK_HIP(hipMemsetAsync(red, 0, sizeof(double) * 2 * C, st));
+  const long nvox = (long)B * D * H * W;
+  const int C4 = C / 4;
+  {
+    HP_PROF("stem_bn_pool_bwd_reduce", st);
+    const int vpb = ET / C4;
+    hipLaunchKernelGGL(k_stem_bwd_reduce, dim3((unsigned)std::min<long>((nvox + vpb - 1) / vpb, 256 * 8)), dim3(ET), 0, st,
+                       (const float4*)z, (const float4*)pooled, (const float4*)dpooled, B, D, H, W, C4, (const float4*)sc,
+                       (const float4*)sh, (const float4*)mean, (const float4*)rstd, red);
+  }
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, nvox, C, mean, rstd, gamma, train, dgamma, dbeta,
+                     ca, cb, cc);
+  {
+    HP_PROF("stem_bn_pool_bwd_apply", st);
+    hipLaunchKernelGGL(k_stem_bwd_apply, dim3(grid_for(nvox * C4)), dim3(ET), 0, st, (const float4*)z, (const float4*)pooled,
+                       (const float4*)dpooled, (float4*)dz, B, D, H, W, C4, (const float4*)sc, (const float4*)sh, (const float4*)ca,
+                       (const float4*)cb, (const float4*)cc);
+  }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

@@ -517,13 +517,72 @@ def deconv_bn_relu(x, deconv, bn):
     return _ConvBnAct.apply(x, deconv.weight, bn.weight, bn.bias, None, bn, 4, 2, 1, True, True)
 
 
+class _StemConvBnReluPool(torch.autograd.Function):
+    """maxpool3(relu(BN(conv7(x)))) -- the normalised 64-channel full-resolution volume is never materialised:
+    the pooling kernel applies BN + ReLU on the fly and the backward recomputes them from the raw conv output."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn):
+        L = _lib.lib()
+        x = x.contiguous()
+        cout = w.shape[0]
+        desc = _desc(x, cout, 7, 1, 3, False)
+        b, d, h, wd_, _ = x.shape
+        st = _stream(x)
+        with torch.cuda.device(x.device):
+            wf, _ = _pack(desc, w, True, False)
+            z = torch.empty(b, d, h, wd_, cout, dtype=torch.float32, device=x.device)
+            M = z.numel() // cout
+            train = bn.training
+            stats = torch.empty(2 * cout, dtype=torch.float64, device=x.device) if train else None
+            _lib.check(L.hp_conv3d_forward(_C.byref(desc), x.data_ptr(), wf.data_ptr(), None, z.data_ptr(), _lib.ptr(stats), st),
+                       "hp_conv3d_forward")
+            mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+            if train:
+                mom = 0.1 if bn.momentum is None else bn.momentum
+                _lib.check(L.hp_bn_train_finalize(stats.data_ptr(), M, cout, bn.eps, mom, mean.data_ptr(), rstd.data_ptr(),
+                                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), st), "hp_bn_train_finalize")
+                bn.num_batches_tracked += 1
+            else:
+                _lib.check(L.hp_bn_eval_stats(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), cout, bn.eps,
+                                              mean.data_ptr(), rstd.data_ptr(), st), "hp_bn_eval_stats")
+            pooled = torch.empty(b, d // 2, h // 2, wd_ // 2, cout, dtype=torch.float32, device=x.device)
+            ws = torch.empty(int(L.hp_stem_bn_pool_workspace_bytes(cout)) // 4 + 4, dtype=torch.float32, device=x.device)
+            _lib.check(L.hp_stem_bn_relu_pool_forward(z.data_ptr(), pooled.data_ptr(), b, d, h, wd_, cout, mean.data_ptr(),
+                                                      rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), st),
+                       "hp_stem_bn_relu_pool_forward")
+        ctx.save_for_backward(x, w, gamma, beta, z, pooled, mean, rstd)
+        ctx.cfg = (desc, train)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        L = _lib.lib()
+        x, w, gamma, beta, z, pooled, mean, rstd = ctx.saved_tensors
+        desc, train = ctx.cfg
+        b, d, h, wd_, cout = z.shape
+        dp = dp.contiguous()
+        st = _stream(x)
+        with torch.cuda.device(x.device):
+            dz = torch.empty_like(z)
+            dgamma = torch.empty_like(gamma)
+            dbeta = torch.empty_like(gamma)
+            ws = torch.empty(int(L.hp_stem_bn_pool_workspace_bytes(cout)) // 4 + 4, dtype=torch.float32, device=x.device)
+            _lib.check(L.hp_stem_bn_relu_pool_backward(z.data_ptr(), pooled.data_ptr(), dp.data_ptr(), dz.data_ptr(), b, d, h, wd_,
+                                                       cout, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                       1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), st),
+                       "hp_stem_bn_relu_pool_backward")
+            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0])
+        return dx, dw, dgamma, dbeta, None
+
+
 def stem_conv_bn_relu_pool(x, conv, bn):
     """x: (B,1,D,H,W) -- identical in memory to channels-last with C = 1."""
     _need_cuda(x, "posenet3d_50")
     b, c, d, h, w = x.shape
     assert c == 1
-    y = _ConvBnAct.apply(x.reshape(b, d, h, w, 1), conv.weight, bn.weight, bn.bias, None, bn, 7, 1, 3, False, True)
-    return _MaxPool3CL.apply(y)
+    return _StemConvBnReluPool.apply(x.reshape(b, d, h, w, 1), conv.weight, bn.weight, bn.bias, bn)
 
 
 def head_conv_to_ncdhw(x, conv):

@@ -133,6 +133,14 @@ int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out
 int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
 int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H, int W,
                                int C, void* stream);
+/* Stem: BatchNorm3d + ReLU + MaxPool3d(3,2,1) fused (posenet3d_50.py:253-257); the normalised 64-channel
+ * full-resolution volume is never written.  z (B,D,H,W,C) is the raw stem convolution output. */
+size_t hp_stem_bn_pool_workspace_bytes(int C);
+int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B, int D, int H, int W, int C, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, void* workspace, void* stream);
+int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled, const float* dpooled, float* dz, int B, int D, int H,
+                                  int W, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  int train, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* [B][V][C] -> [B][C][V] (to_channels_first = 1) or back (0). */
 int hp_layout_transpose(const float* in, float* out, int B, long V, int C, int to_channels_first, void* stream);
 
