@@ -46,11 +46,15 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
     const float4 v = z[i], m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+    // y = z * sc + sh with sc = rstd * gamma, sh = beta - mean * sc: the backward rebuilds the ReLU mask with
+    // exactly this expression
+    const float4 sc = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
+    const float4 sh = make_float4(b.x - m.x * sc.x, b.y - m.y * sc.y, b.z - m.z * sc.z, b.w - m.w * sc.w);
     float4 o;
-    o.x = (v.x - m.x) * r.x * g.x + b.x;
-    o.y = (v.y - m.y) * r.y * g.y + b.y;
-    o.z = (v.z - m.z) * r.z * g.z + b.z;
-    o.w = (v.w - m.w) * r.w * g.w + b.w;
+    o.x = fmaf(v.x, sc.x, sh.x);
+    o.y = fmaf(v.y, sc.y, sh.y);
+    o.z = fmaf(v.z, sc.z, sh.z);
+    o.w = fmaf(v.w, sc.w, sh.w);
     if (res) {
       const float4 q = res[i];
       o.x += q.x;
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
                                                       const float4* __restrict__ z, float4* __restrict__ g_out, long M,
                                                       int C4, const float4* __restrict__ mean,
                                                       const float4* __restrict__ rstd, int relu,
-                                                      double* __restrict__ red) {
+                                                      double* __restrict__ red, const float4* __restrict__ gamma,
+                                                      const float4* __restrict__ beta) {
   __shared__ float4 ssum[ET], sdot[ET];
   const int tid = threadIdx.x;
   const int lanes_per_row = C4 < ET ? C4 : ET;       // threads covering one row pass
@@ -87,18 +92,27 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
     float4 s = make_float4(0, 0, 0, 0), d = make_float4(0, 0, 0, 0);
     if (cq < C4 && my_row < rows_per_pass) {
       const float4 m = mean[cq], r = rstd[cq];
+      // without a residual the ReLU mask follows from z alone: the forward output need not be read
+      float4 sc = make_float4(0, 0, 0, 0), sh = sc;
+      if (relu && !y) {
+        const float4 ga = gamma[cq], be = beta[cq];
+        sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
+        sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
+      }
       for (long row = (long)blockIdx.x * rows_per_pass + my_row; row < M; row += (long)gridDim.x * rows_per_pass) {
         const long i = row * C4 + cq;
         float4 g = dy[i];
+        const float4 v = z[i];
         if (relu) {
-          const float4 yy = y[i];
+          float4 yy;
+          if (y) yy = y[i];
+          else yy = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
           g.x = yy.x > 0.f ? g.x : 0.f;
           g.y = yy.y > 0.f ? g.y : 0.f;
           g.z = yy.z > 0.f ? g.z : 0.f;
           g.w = yy.w > 0.f ? g.w : 0.f;
         }
         if (g_out) g_out[i] = g;
-        const float4 v = z[i];
         s.x += g.x;
         s.y += g.y;
         s.z += g.z;
@@ -485,11 +499,12 @@ extern "C" int hp_bn_apply(const float* z, const float* res, float* y, long M, i
 extern "C" size_t hp_bn_backward_workspace_bytes(int C) { return sizeof(double) * 2 * C + sizeof(float) * 3 * C; }
 
 extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
-                              const float* mean, const float* rstd, const float* gamma, int relu, int train,
-                              float* dgamma, float* dbeta, void* workspace, void* stream) {
+                              const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask,
+                              int relu, int train, float* dgamma, float* dbeta, void* workspace, void* stream) {
   HP_REQUIRE(dy && z && dz && mean && rstd && gamma && workspace && M > 0 && C > 0 && C % 4 == 0,
              "hp_bn_backward: bad argument");
-  HP_REQUIRE(!relu || y, "hp_bn_backward: relu needs the forward output");
+  HP_REQUIRE(!relu || y || beta_for_mask, "hp_bn_backward: relu needs the forward output or beta to rebuild the mask");
+  // y may be NULL when there was no residual: the ReLU mask is then recomputed from z (bit-identical affine map)
   hipStream_t st = (hipStream_t)stream;
   double* red = (double*)workspace;
   float* ca = (float*)(red + 2 * C);
@@ -504,7 +519,8 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
     const int rows_per_pass = C4 < ET ? ET / C4 : 1;
     const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 4);
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(ET), 0, st, (const float4*)dy, (const float4*)y, (const float4*)z,
-                       (float4*)gbuf, M, C4, (const float4*)mean, (const float4*)rstd, relu, red);
+                       (float4*)gbuf, M, C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma,
+                       (const float4*)beta_for_mask);
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, M, C, mean, rstd, gamma, train, dgamma,
                      dbeta, ca, cb, cc);

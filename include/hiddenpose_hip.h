@@ -126,9 +126,10 @@ int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const
 size_t hp_bn_backward_workspace_bytes(int C);
 /* g = dy * [y > 0] (stored to g_out if not NULL: gradient of the residual branch);
  * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL. */
+/* y may be NULL for a unit without residual: the ReLU mask is then rebuilt from z and beta_for_mask. */
 int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
-                   const float* mean, const float* rstd, const float* gamma, int relu, int train, float* dgamma,
-                   float* dbeta, void* workspace, void* stream);
+                   const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask, int relu,
+                   int train, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* MaxPool3d(kernel 3, stride 2, padding 1) (posenet3d_50.py:184), channels-last. */
 int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
 int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H, int W,
