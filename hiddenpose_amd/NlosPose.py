@@ -1,15 +1,18 @@
-"""NlosPose: transient measurement volume -> 24-joint heat-maps.
+"""Top-level transient-to-pose network on HIP kernels.
 
-Drop-in for models/NlosPose.py `NlosPose(cfg)` (:13-59): same submodule names (hence
-the same 423-tensor state_dict; nothing under `feature_propagation.`), same
-`forward(meas (B,1,T,H,W)) -> (heatmap (B,24,T/2,H/2,W/2), refine_feature (B,1,T,H,W))`.
+Same constructor argument (a cfg node), same attribute / state_dict names and the same call contract as the
+reference's models/NlosPose.py: `NlosPose(cfg)(meas)` maps a transient volume (B,1,T,H,W) to
+(heat-maps (B,24,T/2,H/2,W/2), refined volume (B,1,T,H,W)).  Stage order (reference :49-59):
+feature extraction -> light-cone transform over the full time window -> per-volume normalisation to [0,10] ->
+U-Net refinement -> heat-map regression on (feature + refinement).  The LCT owns no parameters, so there is
+nothing under `feature_propagation.` in the state_dict (as in the reference).
 """
 from __future__ import annotations
 
 from torch import nn
 
 from . import _lib
-from . import hip_ops as ops
+from . import hip_ops as K
 from .feature_extraction import FeatureExtraction
 from .feature_propagation import FeaturePropagation
 from .posenet3d_50 import get_pose_net_50
@@ -19,27 +22,24 @@ from .unet3d import UNet3d
 class NlosPose(nn.Module):
     def __init__(self, cfg):
         super().__init__()
-        _lib.lib()  # fail loudly if the HIP extension is missing
-        self.time_begin = 0
-        self.time_end = cfg.MODEL.TIME_SIZE
-        self.feature_extraction = FeatureExtraction(basedim=cfg.MODEL.BASEDIM, in_channels=cfg.MODEL.IN_CHANNELS,
-                                                    stride=1)
-        self.feature_propagation = FeaturePropagation(
-            time_size=cfg.MODEL.TIME_SIZE, image_size=cfg.MODEL.IMAGE_SIZE[0], wall_size=cfg.MODEL.WALL_SIZE,
-            bin_len=cfg.MODEL.BIN_LEN, dnum=cfg.MODEL.DNUM, dev=cfg.DEVICE)
-        if getattr(cfg.MODEL, "PRETRAIN_AUTOENCODER", False):
-            raise NotImplementedError("PRETRAIN_AUTOENCODER loads a pickled module (models/NlosPose.py:34-35); "
-                                      "load its state_dict into .autoencoder instead")
-        self.autoencoder = UNet3d(in_channels=1, n_channels=4)
-        if cfg.MODEL.BACKBONE != "posenet3d_50":
-            raise NotImplementedError(f"backbone {cfg.MODEL.BACKBONE!r}: only posenet3d_50 (config_noise.py:35) is built")
+        _lib.lib()  # the HIP extension is mandatory: fail here, not in the first forward
+        m = cfg.MODEL
+        if getattr(m, "PRETRAIN_AUTOENCODER", False):
+            raise NotImplementedError("a pickled autoencoder module cannot be adopted; load its state_dict into "
+                                      "`.autoencoder` after construction")
+        if m.BACKBONE != "posenet3d_50":
+            raise NotImplementedError(f"backbone {m.BACKBONE!r} is not built (the reference's config selects posenet3d_50)")
+        self.time_begin, self.time_end = 0, m.TIME_SIZE
+        self.feature_extraction = FeatureExtraction(m.BASEDIM, m.IN_CHANNELS, stride=1)
+        self.feature_propagation = FeaturePropagation(image_size=m.IMAGE_SIZE[0], time_size=m.TIME_SIZE,
+                                                      bin_len=m.BIN_LEN, wall_size=m.WALL_SIZE, dnum=m.DNUM,
+                                                      dev=cfg.DEVICE)
+        self.autoencoder = UNet3d(1, 4)
         self.pose_net = get_pose_net_50()
 
     def forward(self, meas):
-        b = meas.shape[0]
-        meas = self.feature_extraction(meas)
-        feature = self.feature_propagation(meas, [self.time_begin] * b, [self.time_end] * b)
-        feature = ops.normalize_feature(feature)
+        n = meas.shape[0]
+        window = ([self.time_begin] * n, [self.time_end] * n)
+        feature = K.normalize_feature(self.feature_propagation(self.feature_extraction(meas), *window))
         refine_feature = self.autoencoder(feature)
-        output = self.pose_net(ops.add(feature, refine_feature))
-        return output, refine_feature
+        return self.pose_net(K.add(feature, refine_feature)), refine_feature

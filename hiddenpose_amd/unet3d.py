@@ -1,51 +1,63 @@
-"""3-D U-Net "autoencoder" of NlosPose.
+"""Volume-refinement U-Net ("autoencoder") of NlosPose, on HIP kernels.
 
-Drop-in for unet/unet3d.py `UNet3d(in_channels, n_channels)` (:74-104):
-DoubleConv = (Conv3d 3^3 pad 1 -> GroupNorm(4) -> ReLU) x 2 (:11-28), Down =
-MaxPool3d(2) + DoubleConv (:31-39), Up = trilinear x2 align_corners=True, pad,
-cat([skip, up]), DoubleConv (:42-62), Out = 1^3 conv (:65-71).  Same state_dict keys.
+API and checkpoint layout follow unet/unet3d.py of the reference: `UNet3d(in_channels, n_channels)`
+with sub-modules conv / enc1..enc4 / dec1..dec4 / out, whose parameters live under
+`<stage>.double_conv.{0,1,3,4}`, `<enc>.encoder.1.*`, `<dec>.conv.*`, `out.conv.*`.
+Per stage (reference lines): conv3^3+GroupNorm(4)+ReLU twice (:11-28); max-pool 2 before an encoder stage (:31-39);
+trilinear x2 upsampling with align_corners=True, concatenation [skip, up], then the double conv (:42-62);
+final 1^3 convolution (:65-71).  Every operation is a kernel of libhiddenpose_hip.so
+(csrc/dconv_kernels.hip, csrc/unet_kernels.hip); parameters are held by stock nn.Conv3d / nn.GroupNorm
+objects only so that the state_dict keys match.
 """
 from __future__ import annotations
 
-import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from . import hip_ops as ops
+from . import hip_ops as K
+
+_GROUPS = 4
+
+
+def _conv_gn(cin: int, cout: int):
+    return [nn.Conv3d(cin, cout, kernel_size=3, stride=1, padding=1), nn.GroupNorm(_GROUPS, cout), nn.Identity()]
 
 
 class DoubleConv(nn.Module):
-    def __init__(self, in_channels, out_channels, num_groups=4):
+    def __init__(self, in_channels, out_channels, num_groups=_GROUPS):
         super().__init__()
-        self.double_conv = nn.Sequential(
-            nn.Conv3d(in_channels, out_channels, 3, 1, 1), nn.GroupNorm(num_groups, out_channels), nn.Identity(),
-            nn.Conv3d(out_channels, out_channels, 3, 1, 1), nn.GroupNorm(num_groups, out_channels), nn.Identity())
+        assert num_groups == _GROUPS
+        self.double_conv = nn.Sequential(*_conv_gn(in_channels, out_channels), *_conv_gn(out_channels, out_channels))
 
     def forward(self, x):
-        s = self.double_conv
-        x = ops.conv3_gn_relu(x, s[0].weight, s[0].bias, s[1].weight, s[1].bias, s[1].num_groups, s[1].eps)
-        return ops.conv3_gn_relu(x, s[3].weight, s[3].bias, s[4].weight, s[4].bias, s[4].num_groups, s[4].eps)
+        for conv_idx in (0, 3):
+            conv, gn = self.double_conv[conv_idx], self.double_conv[conv_idx + 1]
+            x = K.conv3_gn_relu(x, conv.weight, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps)
+        return x
 
 
 class Down(nn.Module):
+    """2x max-pool, then DoubleConv; parameters under `encoder.1`."""
+
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.encoder = nn.Sequential(nn.Identity(), DoubleConv(in_channels, out_channels))
 
     def forward(self, x):
-        return self.encoder[1](ops.max_pool3d_2(x))
+        return self.encoder[1](K.max_pool3d_2(x))
 
 
 class Up(nn.Module):
+    """Upsample the coarse tensor, stack it behind the skip tensor, DoubleConv; parameters under `conv`."""
+
     def __init__(self, in_channels, out_channels, trilinear=True):
         super().__init__()
-        assert trilinear, "only the trilinear variant used by NlosPose is provided"
+        if not trilinear:
+            raise NotImplementedError("NlosPose uses the trilinear variant only")
         self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2):
-        # upsample x1 and concatenate [skip, up] (the reference's F.pad is a no-op for even sizes)
-        return self.conv(ops.upsample_cat(x1, x2))
+    def forward(self, coarse, skip):
+        return self.conv(K.upsample_cat(coarse, skip))
 
 
 class Out(nn.Module):
@@ -54,34 +66,34 @@ class Out(nn.Module):
         self.conv = nn.Conv3d(in_channels, out_channels, kernel_size=1)
 
     def forward(self, x):
-        return ops.conv3d(x, self.conv.weight, self.conv.bias)
+        return K.conv3d(x, self.conv.weight, self.conv.bias)
 
 
 class UNet3d(nn.Module):
+    # (stage name, kind, input multiple of n, output multiple of n); decoder inputs count skip + upsampled channels
+    _PLAN = (("enc1", Down, 1, 2), ("enc2", Down, 2, 4), ("enc3", Down, 4, 8), ("enc4", Down, 8, 8),
+             ("dec1", Up, 16, 4), ("dec2", Up, 8, 2), ("dec3", Up, 4, 1), ("dec4", Up, 2, 1))
+
     def __init__(self, in_channels, n_channels):
         super().__init__()
         _lib.lib()
         self.in_channels, self.n_channels = in_channels, n_channels
-        n = n_channels
-        self.conv = DoubleConv(in_channels, n)
-        self.enc1, self.enc2, self.enc3, self.enc4 = Down(n, 2 * n), Down(2 * n, 4 * n), Down(4 * n, 8 * n), Down(8 * n, 8 * n)
-        self.dec1, self.dec2, self.dec3, self.dec4 = Up(16 * n, 4 * n), Up(8 * n, 2 * n), Up(4 * n, n), Up(2 * n, n)
-        self.out = Out(n, in_channels)
+        self.conv = DoubleConv(in_channels, n_channels)
+        for name, kind, mi, mo in self._PLAN:
+            setattr(self, name, kind(mi * n_channels, mo * n_channels))
+        self.out = Out(n_channels, in_channels)
 
     def forward(self, x):
-        x1 = self.conv(x)
-        x2 = self.enc1(x1)
-        x3 = self.enc2(x2)
-        x4 = self.enc3(x3)
-        x5 = self.enc4(x4)
-        o = self.dec1(x5, x4)
-        o = self.dec2(o, x3)
-        o = self.dec3(o, x2)
-        o = self.dec4(o, x1)
-        return self.out(o)
+        skips = [self.conv(x)]
+        for name in ("enc1", "enc2", "enc3", "enc4"):
+            skips.append(getattr(self, name)(skips[-1]))
+        y = skips.pop()
+        for name in ("dec1", "dec2", "dec3", "dec4"):
+            y = getattr(self, name)(y, skips.pop())
+        return self.out(y)
 
 
 def freeze_layer(model):
-    """unet/unet3d.py:107-119"""
-    for _, p in model.named_parameters():
-        p.requires_grad = False
+    """Stop training of every parameter of `model` (reference helper of the same name)."""
+    for p in model.parameters():
+        p.requires_grad_(False)
