@@ -38,6 +38,7 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
+MFMA_BF16_PEAK_TFLOPS = 2516.8  # same guide: dense bf16 MFMA = 16 x the f32-input rate (~2.5 PF)
 
 
 def posenet_conv_flops(T: int, N: int, B: int) -> dict:
@@ -157,7 +158,7 @@ def bench_sformer(args):
     print(json.dumps({
         "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.conv_precision if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"NlosPoseSformer forward, batch {B}, 16 frames x 128x128, patch 4, dim 256, depth 8, "
                                "8 heads x 32, random-init weights"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},
@@ -229,6 +230,9 @@ def main():
     ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS) + ["sformer", "highres"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-precision", default="fp32", choices=["fp32", "bf16", "bf16x3", "bf16x6"],
+                    help="regressor convolution GEMM arithmetic; bf16 = BASELINE.json configs[2] (bf16 with fp32 LCT). "
+                         "The headline metric (configs[1]) is fp32, the default.")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     args = ap.parse_args()
 
@@ -262,7 +266,11 @@ def main():
     T, N, B = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
-    cfg = make_cfg(T, N, device=local)
+    cfg = make_cfg(T, N, device=local, conv_precision=args.conv_precision)
+    bf16 = args.conv_precision != "fp32"
+    # split modes issue 3 / 6 bf16 MFMAs per algorithmic product: the useful-FLOP ceiling shrinks accordingly
+    mfma_terms = {"fp32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}[args.conv_precision]
+    mfma_peak = round(MFMA_BF16_PEAK_TFLOPS / mfma_terms, 1) if bf16 else MFMA_F32_PEAK_TFLOPS
     seed_everything(410)
     model = NlosPose(cfg).to(dev)
     model.train()
@@ -321,9 +329,10 @@ def main():
                       else f"samples/sec ({N}x{N}x{T} meas) fwd+bwd",
             "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.conv_precision if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
-                                   f"batch {B}/GPU, fp32, random-init weights", "global_batch": B * world,
+                                   f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
+                                   "accumulation) with fp32 LCT, U-Net, norms, losses and fp32 tensors in HBM" if bf16 else "fp32") + ", random-init weights", "global_batch": B * world,
                        "parallelism": f"dp{world}", "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
                        "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
             "loss": round(float(loss.item()), 6),
@@ -337,14 +346,14 @@ def main():
                 # one profiling name covers every layer's launch of that kernel family:
                 # achieved = total algorithmic FLOPs of the family / total time of its launches
                 ach = conv[name] * args.steps / (ms / 1e3) / 1e12
-                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches": n,
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": mfma_peak,
+                        "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4), "traffic": None, "launches": n,
                         "avg_launch_us": round(1e3 * ms / n, 2),
                         "gflop_per_step": round(conv[name] / 1e9, 1)}
                 # HBM bytes of this kernel family per step from the committed PMC passes (rocprofv3 --pmc
                 # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH x2 on gfx950); only valid for the same workload
                 pmc = os.path.join(ROOT, "profiles", "round1_t512_pmc_hbm_traffic.json")
-                if args.workload == "t512" and B == 4 and os.path.exists(pmc):
+                if args.workload == "t512" and B == 4 and not bf16 and os.path.exists(pmc):
                     fam = json.load(open(pmc))
                     key = name if name in fam else None
                     if key:

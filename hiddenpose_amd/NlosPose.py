@@ -35,7 +35,7 @@ class NlosPose(nn.Module):
                                                       bin_len=m.BIN_LEN, wall_size=m.WALL_SIZE, dnum=m.DNUM,
                                                       dev=cfg.DEVICE)
         self.autoencoder = UNet3d(1, 4)
-        self.pose_net = get_pose_net_50()
+        self.pose_net = get_pose_net_50(getattr(m, "CONV_PRECISION", "fp32"))
 
     def forward(self, meas):
         n = meas.shape[0]

@@ -86,7 +86,7 @@ SIGNATURES = {
 
 class ConvDesc(C.Structure):
     """Mirror of `hp_conv_desc` (include/hiddenpose_hip.h)."""
-    _fields_ = [(n, C.c_int) for n in ("B", "Di", "Hi", "Wi", "Cin", "Cout", "k", "stride", "pad", "transposed")]
+    _fields_ = [(n, C.c_int) for n in ("B", "Di", "Hi", "Wi", "Cin", "Cout", "k", "stride", "pad", "transposed", "precision")]
 
 
 def lib() -> C.CDLL:

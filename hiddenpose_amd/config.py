@@ -67,6 +67,9 @@ def get_cfg_defaults() -> CfgNode:
         TIME_SIZE=512, IMAGE_SIZE=[256, 256], HEATMAP_SIZE=[64, 64, 64], MODE="lct",
         COORD_REPRESENTATION="3DHeatmap", NUM_JOINTS=24, BACKBONE="posenet3d_50",
         PRETRAIN_AUTOENCODER=False, PRETRAIN_AUTOENCODER_PATH="./lib/nlos_unet.pth",
+        # not a reference key: arithmetic of the regressor's convolution GEMMs, "fp32" (default, exact) or
+        # "bf16" (bf16 operands / fp32 accumulation; LCT, U-Net, norms and losses stay fp32)
+        CONV_PRECISION="fp32",
     )
     c.DATASET = CfgNode(NAME="NlosPoseDataset", NUM_JOINTS=24, HEATMAP_SIZE=[64, 64, 64], DAWNSAMPLE_CNT=1)
     c.TRAIN = CfgNode(OPTIMIZER="adam", LR=0.001, LR_FACTOR=0.2, LR_STEP=[2, 4, 13], BATCH_SIZE=2,
@@ -85,7 +88,7 @@ def update_config_t128_128x128(cfg) -> None:
     cfg.freeze()
 
 
-def make_cfg(T: int, N: int, bin_len: float | None = None, device=0) -> CfgNode:
+def make_cfg(T: int, N: int, bin_len: float | None = None, device=0, conv_precision: str = "fp32") -> CfgNode:
     """Config for a (T, N, N) transient; bin_len defaults to the value that keeps the
     time range at 5.12 m as in both reference shapes (128 x 0.04, 512 x 0.01)."""
     c = get_cfg_defaults()
@@ -95,4 +98,5 @@ def make_cfg(T: int, N: int, bin_len: float | None = None, device=0) -> CfgNode:
     c.MODEL.BIN_LEN = 5.12 / T if bin_len is None else bin_len
     c.DATASET.HEATMAP_SIZE = [N // 2, N // 2, T // 2]
     c.MODEL.HEATMAP_SIZE = [N // 2, N // 2, T // 2]
+    c.MODEL.CONV_PRECISION = conv_precision
     return c

@@ -27,6 +27,18 @@
 namespace hp {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+// four fp32 -> four bf16 (round to nearest even; two v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
+  const bf16x2 lo = __builtin_convertvector((f32x2){v.x, v.y}, bf16x2);
+  const bf16x2 hi = __builtin_convertvector((f32x2){v.z, v.w}, bf16x2);
+  return (bf16x4){lo[0], lo[1], hi[0], hi[1]};
+}
 
 enum IgemmMode { MODE_CONV = 0, MODE_DECONV = 1, MODE_DGRAD_S2K3 = 2, MODE_STEM = 3 };
 
@@ -61,7 +73,44 @@ __device__ __forceinline__ void grid_coords(const IgemmGeom& g, long m, int& b, 
   }
 }
 
+// Split of four fp32 values into NP bf16 planes: plane 0 = bf16(v), plane p = bf16(v - sum of earlier planes).
+// NP = 1 is plain bf16 rounding; NP = 2 keeps 16 significant bits, NP = 3 all 24 (each residual is exact in fp32).
+template <int NP>
+__device__ __forceinline__ void split_bf16(const float4 v, bf16x4 (&out)[NP]) {
+  float4 r = v;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    out[p] = to_bf16x4(r);
+    if (p + 1 < NP) {
+      r.x -= (float)out[p][0];
+      r.y -= (float)out[p][1];
+      r.z -= (float)out[p][2];
+      r.w -= (float)out[p][3];
+    }
+  }
+}
+// Products kept for an NP-plane split of both operands, smallest terms first: every pair (pa, pb) with
+// pa + pb < NP.  NP = 1: 1 MFMA, 2: 3 MFMAs (error ~2^-16 per product), 3: 6 MFMAs (error ~2^-24, the fp32 level).
+template <int NP>
+struct SplitTerms;
+template <>
+struct SplitTerms<1> {
+  static constexpr int N = 1;
+  static constexpr int A[1] = {0}, B[1] = {0};
+};
+template <>
+struct SplitTerms<2> {
+  static constexpr int N = 3;
+  static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0};
+};
+template <>
+struct SplitTerms<3> {
+  static constexpr int N = 6;
+  static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0};
+};
+
 constexpr int BM = 128, BK = 32, LDK = BK + 1, CT = 256;
+constexpr int LDH = BK + 8;  // bf16 tile row: 80 bytes, so the 16-byte fragment reads of 32 rows spread over all banks
 
 __host__ __device__ inline int class_ntaps(const IgemmGeom& g, int cls) {
   switch (g.mode) {
@@ -109,16 +158,22 @@ struct TileCfg {
   static constexpr int TN = BN / (WN * 32);
 };
 
-template <int BN, bool STEM, bool STATS>
+template <int BN, bool STEM, bool STATS, int NP>
 __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, float* __restrict__ Y,
                                               double* __restrict__ stats, const float* __restrict__ addend,
                                               IgemmGeom g) {
   using C = TileCfg<BN>;
   // one LDS arena: A and B tiles during the K loop, then the output staging tile of the epilogue
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+  constexpr bool BF = NP > 0;  // NP = 0: exact-fp32 MFMA; NP >= 1: bf16 MFMA on NP operand planes
+  constexpr int NPL = NP > 0 ? NP : 1;
+  constexpr int ARENA = (BM + BN) * LDK > NP * (BM + BN) * LDH / 2 ? (BM + BN) * LDK : NP * (BM + BN) * LDH / 2;
+  __shared__ __attribute__((aligned(16))) float smem[ARENA];
   float* const As = smem;
   float* const Bs = smem + BM * LDK;
+  // BF: the same arena holds the tiles as NP bf16 planes each (operands split once, on the way into LDS)
+  __bf16* const Ah = (__bf16*)smem;
+  __bf16* const Bh = Ah + NPL * BM * LDH;
   __shared__ float red[STATS ? 2 * BN * C::WM : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
@@ -194,6 +249,23 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
     }
   };
   auto store_tile = [&]() {
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16x4 pl[NPL];
+        split_bf16<NPL>(ra[i], pl);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(bf16x4*)(Ah + (p * BM + r0 + 32 * i) * LDH + kq * 4) = pl[p];
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) {
+        bf16x4 pl[NPL];
+        split_bf16<NPL>(rbw[i], pl);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *(bf16x4*)(Bh + (p * BN + r0 + 32 * i) * LDH + kq * 4) = pl[p];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float* d = As + (r0 + 32 * i) * LDK + kq * 4;
@@ -222,10 +294,35 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
 
   const float* ap = As + (wm * C::TM * 32 + (lane & 31)) * LDK + (lane >> 5);
   const float* bp = Bs + (wn * C::TN * 32 + (lane & 31)) * LDK + (lane >> 5);
+  const __bf16* ahp = Ah + (wm * C::TM * 32 + (lane & 31)) * LDH + 8 * (lane >> 5);
+  const __bf16* bhp = Bh + (wn * C::TN * 32 + (lane & 31)) * LDH + 8 * (lane >> 5);
   // kt = -1 is the prologue: one call site for the gather keeps the pipeline uniform
   for (int kt = -1; kt < KT; ++kt) {
     if (kt + 1 < KT) load_tile(kt + 1);
-    if (kt >= 0) {
+    if (BF && kt >= 0) {
+      // v_mfma_f32_32x32x16_bf16: lane (row = lane&31, half = lane>>5) feeds k = 8*half .. 8*half+7
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 ha[NPL][C::TM], hb[NPL][C::TN];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+          for (int i = 0; i < C::TM; ++i) ha[p][i] = *(const bf16x8*)(ahp + (p * BM + i * 32) * LDH + ks * 16);
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j) hb[p][j] = *(const bf16x8*)(bhp + (p * BN + j * 32) * LDH + ks * 16);
+        }
+        using ST = SplitTerms<NPL>;
+#pragma unroll
+        for (int t = 0; t < ST::N; ++t)
+#pragma unroll
+          for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ST::A[t]][i], hb[ST::B[t]][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    if (!BF && kt >= 0) {
       // fragments of step kk+1 are fetched from LDS while the MFMAs of step kk run (two register sets)
       float fa[2][C::TM], fb[2][C::TN];
 #pragma unroll
@@ -263,7 +360,7 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
     // The accumulators leave through LDS so that every lane moves 16 contiguous bytes of one output row
     // (bias / shortcut-gradient addend are read the same way); 64 tile rows per round.
     constexpr int LDO = BN + 4, Q = BN / 4;
-    static_assert(64 * LDO <= (BM + BN) * LDK, "staging tile must fit the arena");
+    static_assert(64 * LDO <= ARENA, "staging tile must fit the arena");
     static_assert(C::WM == 2 && C::TM == 2, "epilogue assumes 2 waves x 2 MFMA tiles along M");
     const bool vec_ok = (g.Nout & 3) == 0;
 #pragma unroll
@@ -382,7 +479,7 @@ constexpr int WG_KM = 32;  // voxels per step
 // step, global loads of step s+1 in flight while the MFMAs of step s run.  With TT = 64 a block may own
 // NTAP consecutive taps of a single-class convolution: the dY tile is staged once and reused by the
 // NTAP gathered X tiles (1 + NTAP LDS fragment reads feed NTAP MFMAs).
-template <bool STEM, int TT, int NTAP>
+template <bool STEM, int TT, int NTAP, int NP>
 __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
                                               float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit,
                                               int tiles_total, int tap_groups) {
@@ -391,8 +488,18 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
   constexpr int RPT = WG_KM / RPP;      // rows per thread
   constexpr int WT = TT / 64;           // 32x32 tiles per wave per dim
   static_assert(NTAP == 1 || TT == 64, "multi-tap blocks use the 64x64 tile");
-  __shared__ float Ys[WG_KM * TT];
-  __shared__ float Xs[NTAP * WG_KM * TT];
+  constexpr bool BF = NP > 0;
+  constexpr int NPL = NP > 0 ? NP : 1;
+  constexpr int LDT = TT + 32;
+  constexpr int YSZ = WG_KM * TT > NP * WG_KM * LDT / 2 ? WG_KM * TT : NP * WG_KM * LDT / 2;  // floats
+  __shared__ __attribute__((aligned(16))) float Ys[YSZ];
+  __shared__ __attribute__((aligned(16))) float Xs[NTAP * YSZ];
+  // BF: the tiles are kept as bf16 [voxel][TT + 32]; the matrix cores want 8 consecutive voxels (the GEMM K
+  // axis) per lane, which the transposing LDS read (ds_read_b64_tr_b16) delivers from this row-major
+  // image.  Row stride = 16 dwords mod 32, so the 4 rows x 64 bytes one half-wave touches cover all banks.
+  // planes: Yh[p][voxel][LDT], Xh[tap][p][voxel][LDT]
+  __bf16* const Yh = (__bf16*)Ys;
+  __bf16* const Xh = (__bf16*)Xs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, tap group fastest: blocks that run together share the same voxel range, so the dY rows and
   // the (shifted) X rows they gather are served by L2 / Infinity Cache instead of being re-fetched per tap
@@ -486,12 +593,69 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
     __syncthreads();  // fragment reads of the previous step are done
 #pragma unroll
     for (int h = 0; h < RPT; ++h) {
-      *(float4*)(Ys + (sr + RPP * h) * TT + sq * 4) = vy[h];
+      if constexpr (BF) {
+        bf16x4 pl[NPL];
+        split_bf16<NPL>(vy[h], pl);
 #pragma unroll
-      for (int t = 0; t < NTAP; ++t) *(float4*)(Xs + (t * WG_KM + sr + RPP * h) * TT + sq * 4) = vx[t][h];
+        for (int p = 0; p < NPL; ++p) *(bf16x4*)(Yh + (p * WG_KM + sr + RPP * h) * LDT + sq * 4) = pl[p];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          split_bf16<NPL>(vx[t][h], pl);
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            *(bf16x4*)(Xh + ((t * NPL + p) * WG_KM + sr + RPP * h) * LDT + sq * 4) = pl[p];
+        }
+      } else {
+        *(float4*)(Ys + (sr + RPP * h) * TT + sq * 4) = vy[h];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) *(float4*)(Xs + (t * WG_KM + sr + RPP * h) * TT + sq * 4) = vx[t][h];
+      }
     }
     __syncthreads();
     if (mb + WG_KM < mend) load_step(mb + WG_KM);
+    if constexpr (BF) {
+      // 16-lane group gq of the wave: voxels 8*(gq>>1) .. +7 of the K step, channels 16*(gq&1) .. +15 of the
+      // 32-wide tile; lane 4q+p of the group addresses row q, columns 4p .. 4p+3 (two reads: rows +0, +4)
+      const int gq = lane >> 4, li = lane & 15;
+      const int trow = 8 * (gq >> 1) + (li >> 2), tcol = 16 * (gq & 1) + 4 * (li & 3);
+      typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+      auto tr8 = [&](const __bf16* base) -> bf16x8 {
+        union {
+          s16x4 h[2];
+          bf16x8 f;
+        } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * LDT));
+        return u.f;
+      };
+      using ST = SplitTerms<NPL>;
+#pragma unroll
+      for (int ks = 0; ks < WG_KM / 16; ++ks) {
+        bf16x8 ha[NPL][WT];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+          for (int i = 0; i < WT; ++i)
+            ha[p][i] = tr8(Yh + (p * WG_KM + ks * 16 + trow) * LDT + wn * (TT / 2) + i * 32 + tcol);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          bf16x8 hb[NPL][WT];
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+              hb[p][j] = tr8(Xh + ((t * NPL + p) * WG_KM + ks * 16 + trow) * LDT + wc * (TT / 2) + j * 32 + tcol);
+#pragma unroll
+          for (int u = 0; u < ST::N; ++u)
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+              for (int j = 0; j < WT; ++j)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ST::A[u]][i], hb[ST::B[u]][j], acc[t][i][j], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     // two fragment register sets: step kk+1 is read from LDS while the MFMAs of step kk run
     float fa[2][WT], fb[2][NTAP][WT];
     auto frag = [&](int set, int kk) {
@@ -690,6 +854,7 @@ struct ConvPlan {
   IgemmGeom fwd, dgrad, wgrad;
   int fwd_classes = 1, dgrad_classes = 1, wgrad_tapsum = 1;
   bool stem = false, dgrad_zero_fill = false;
+  int planes = 0;
 };
 
 static void set_shifts(IgemmGeom& g) {
@@ -703,6 +868,8 @@ static void set_shifts(IgemmGeom& g) {
 
 static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
   HP_REQUIRE(d.B >= 1 && d.Cin >= 1 && d.Cout >= 1, "conv: bad channel/batch sizes");
+  HP_REQUIRE(d.precision >= HP_PRECISION_FP32 && d.precision <= HP_PRECISION_BF16X6, "conv: unknown precision %d", d.precision);
+  p.planes = d.precision;  // HP_PRECISION_* = number of bf16 operand planes (0: exact-fp32 MFMA)
   const int k = d.k, s = d.stride, pad = d.pad;
   IgemmGeom f{};
   if (!d.transposed) {
@@ -768,28 +935,39 @@ static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
   return HP_OK;
 }
 
-template <bool STEM, bool STATS>
+template <bool STEM, bool STATS, int NP>
 static void launch_igemm_bn(const IgemmGeom& g, int classes, const float* X, const float* W, const float* bias, float* Y,
                             double* stats, const float* addend, hipStream_t st) {
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (g.Nout > 64) {
-    hipLaunchKernelGGL((k_igemm<128, STEM, STATS>), dim3(mt, (g.Nout + 127) / 128, classes), dim3(CT), 0, st, X, W,
+    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP>), dim3(mt, (g.Nout + 127) / 128, classes), dim3(CT), 0, st, X, W,
                        bias, Y, stats, addend, g);
   } else if (g.Nout > 32) {
-    hipLaunchKernelGGL((k_igemm<64, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
+    hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
   } else {
-    hipLaunchKernelGGL((k_igemm<32, STEM, STATS>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
+    hipLaunchKernelGGL((k_igemm<32, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
   }
 }
 
-static void launch_igemm(const IgemmGeom& g, int classes, bool stem, const float* X, const float* W, const float* bias,
-                         float* Y, double* stats, const float* addend, hipStream_t st) {
+template <int NP>
+static void launch_igemm_p(const IgemmGeom& g, int classes, bool stem, const float* X, const float* W, const float* bias,
+                           float* Y, double* stats, const float* addend, hipStream_t st) {
   if (stem) {
-    if (stats) launch_igemm_bn<true, true>(g, classes, X, W, bias, Y, stats, addend, st);
-    else launch_igemm_bn<true, false>(g, classes, X, W, bias, Y, stats, addend, st);
+    if (stats) launch_igemm_bn<true, true, NP>(g, classes, X, W, bias, Y, stats, addend, st);
+    else launch_igemm_bn<true, false, NP>(g, classes, X, W, bias, Y, stats, addend, st);
   } else {
-    if (stats) launch_igemm_bn<false, true>(g, classes, X, W, bias, Y, stats, addend, st);
-    else launch_igemm_bn<false, false>(g, classes, X, W, bias, Y, stats, addend, st);
+    if (stats) launch_igemm_bn<false, true, NP>(g, classes, X, W, bias, Y, stats, addend, st);
+    else launch_igemm_bn<false, false, NP>(g, classes, X, W, bias, Y, stats, addend, st);
+  }
+}
+
+static void launch_igemm(const IgemmGeom& g, int classes, bool stem, int planes, const float* X, const float* W,
+                         const float* bias, float* Y, double* stats, const float* addend, hipStream_t st) {
+  switch (planes) {
+    case 1: launch_igemm_p<1>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
+    case 2: launch_igemm_p<2>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
+    case 3: launch_igemm_p<3>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
+    default: launch_igemm_p<0>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
   }
 }
 
@@ -859,7 +1037,7 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
   {
     HP_PROF(p.stem ? "conv_igemm_stem" : d->transposed ? "conv_igemm_deconv" : d->k == 1 ? "conv_igemm_k1" : "conv_igemm_k3", st);
-    launch_igemm(p.fwd, p.fwd_classes, p.stem, x, w_fwd, bias, y, stats, nullptr, st);
+    launch_igemm(p.fwd, p.fwd_classes, p.stem, p.planes, x, w_fwd, bias, y, stats, nullptr, st);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
@@ -891,7 +1069,7 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
   }
   {
     HP_PROF("conv_igemm_dgrad", st);
-    launch_igemm(p.dgrad, p.dgrad_classes, false, dy, w_dgrad, nullptr, dx, nullptr, addend, st);
+    launch_igemm(p.dgrad, p.dgrad_classes, false, p.planes, dy, w_dgrad, nullptr, dx, nullptr, addend, st);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
@@ -920,10 +1098,24 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
   dim3 grid((unsigned)((long)tiles_total * tap_groups * msplit));
   {
     HP_PROF("conv_wgrad", st);
-    if (p.stem) hipLaunchKernelGGL((k_wgrad<true, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
-    else if (TT == 128) hipLaunchKernelGGL((k_wgrad<false, 128, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
-    else if (multitap) hipLaunchKernelGGL((k_wgrad<false, 64, 4>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
-    else hipLaunchKernelGGL((k_wgrad<false, 64, 1>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+#define HP_WGRAD_P(STEM_, TT_, NTAP_, NP_)                                                                   \
+  hipLaunchKernelGGL((k_wgrad<STEM_, TT_, NTAP_, NP_>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, \
+                     (int)msplit, tiles_total, tap_groups)
+#define HP_WGRAD(STEM_, TT_, NTAP_)                                                                                   \
+  do {                                                                                                               \
+    switch (p.planes) {                                                                                              \
+      case 1: HP_WGRAD_P(STEM_, TT_, NTAP_, 1); break;                                                               \
+      case 2: HP_WGRAD_P(STEM_, TT_, NTAP_, 2); break;                                                               \
+      case 3: HP_WGRAD_P(STEM_, TT_, NTAP_, 3); break;                                                               \
+      default: HP_WGRAD_P(STEM_, TT_, NTAP_, 0); break;                                                              \
+    }                                                                                                                \
+  } while (0)
+    if (p.stem) HP_WGRAD(true, 64, 1);
+    else if (TT == 128) HP_WGRAD(false, 128, 1);
+    else if (multitap) HP_WGRAD(false, 64, 4);
+    else HP_WGRAD(false, 64, 1);
+#undef HP_WGRAD
+#undef HP_WGRAD_P
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

@@ -315,9 +315,30 @@ def upsample_cat(x1, skip):
 # ---------------------------------------------------------------- posenet3d_50 (rows P1-P3)
 # Channels-last (B, D, H, W, C) fp32 tensors between units; every kernel is in libhiddenpose_hip.so
 # (csrc/conv_kernels.hip: exact-fp32 MFMA implicit GEMM; csrc/norm_kernels.hip: BN / pool / layout).
+_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}  # HP_PRECISION_* of include/hiddenpose_hip.h
+_conv_precision = 0
+
+
+def set_conv_precision(name: str) -> str:
+    """Arithmetic of the regressor's convolution GEMMs: 'fp32' (exact-fp32 MFMA, default), 'bf16'
+    (bf16 operands, fp32 accumulation; tensors stay fp32), or the split modes 'bf16x3' / 'bf16x6' (each fp32
+    operand as 2 / 3 bf16 planes, 3 / 6 plane products: ~2^-16 / ~2^-24 relative error per product).  Returns the previous setting.  The choice is
+    recorded in the descriptor each forward call builds, so a backward pass uses what its forward used."""
+    global _conv_precision
+    if name not in _PRECISIONS:
+        raise ValueError(f"conv precision must be one of {sorted(_PRECISIONS)}, got {name!r}")
+    prev = get_conv_precision()
+    _conv_precision = _PRECISIONS[name]
+    return prev
+
+
+def get_conv_precision() -> str:
+    return next(k for k, v in _PRECISIONS.items() if v == _conv_precision)
+
+
 def _desc(x_cl, cout, k, stride, pad, transposed):
     b, d, h, w, cin = x_cl.shape
-    return _lib.ConvDesc(b, d, h, w, cin, cout, k, stride, pad, 1 if transposed else 0)
+    return _lib.ConvDesc(b, d, h, w, cin, cout, k, stride, pad, 1 if transposed else 0, _conv_precision)
 
 
 def _out_dims(desc):

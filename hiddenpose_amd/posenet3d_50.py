@@ -73,6 +73,8 @@ class DeconvHead(nn.Module):
 
 
 class ResNet(nn.Module):
+    conv_precision = "fp32"  # "bf16": bf16-operand MFMA for every convolution GEMM (hip_ops.set_conv_precision)
+
     def __init__(self, n_input_channels=1):
         super().__init__()
         _lib.lib()
@@ -103,10 +105,16 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = ops.stem_conv_bn_relu_pool(x, self.conv1, self.bn1)
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        return self.head(x)
+        prev = ops.set_conv_precision(self.conv_precision)
+        try:
+            x = ops.stem_conv_bn_relu_pool(x, self.conv1, self.bn1)
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            return self.head(x)
+        finally:
+            ops.set_conv_precision(prev)
 
 
-def get_pose_net_50():
-    return ResNet(n_input_channels=1)
+def get_pose_net_50(conv_precision: str = "fp32"):
+    net = ResNet(n_input_channels=1)
+    net.conv_precision = conv_precision
+    return net

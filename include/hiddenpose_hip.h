@@ -93,12 +93,29 @@ int hp_lct_plan_get_invpsf(const hp_lct_plan* plan, float* invpsf_re, float* inv
  * Weights are used in a packed K-contiguous layout ([tap][Cout][Cin]; for the
  * data gradient [tap][Cin][Cout]) produced by hp_conv3d_pack_weight from the
  * torch layout and converted back for gradients by hp_conv3d_unpack_wgrad.
+ *
+ * precision selects the arithmetic of the three GEMMs (tensors stay fp32 in HBM):
+ *   HP_PRECISION_FP32  v_mfma_f32_32x32x2_f32, bit-equal to an fp32 fmaf chain (default);
+ *   HP_PRECISION_BF16  both operands rounded to bf16 (RNE) on the way into LDS,
+ *                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the
+ *                      "bf16 with fp32 LCT" training configuration (BASELINE.json configs[2]);
+ *   HP_PRECISION_BF16X3 / _BF16X6  each fp32 operand split into 2 / 3 bf16 planes
+ *                      (value, residual, residual of the residual) and the 3 / 6 plane
+ *                      products with pa + pb < planes accumulated in fp32 on the bf16 matrix
+ *                      cores: ~2^-16 / ~2^-24 relative error per product (X6 = the fp32
+ *                      level, not bit-identical to FP32).  Opt-in; never the default.
+ * The value is the number of bf16 operand planes.
  * ---------------------------------------------------------------------- */
+#define HP_PRECISION_FP32 0
+#define HP_PRECISION_BF16 1
+#define HP_PRECISION_BF16X3 2
+#define HP_PRECISION_BF16X6 3
 typedef struct hp_conv_desc {
   int B, Di, Hi, Wi; /* input volume */
   int Cin, Cout;
   int k, stride, pad;
   int transposed; /* 0: Conv3d, 1: ConvTranspose3d */
+  int precision;  /* HP_PRECISION_* */
 } hp_conv_desc;
 
 size_t hp_conv3d_packed_weight_elems(const hp_conv_desc* d);

@@ -34,25 +34,45 @@ CASES = [
 ]
 
 
+def _bf16_grid(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("name,cin,cout,k,s,p,tr,dims", CASES, ids=[c[0] for c in CASES])
-def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims):
+def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims, precision):
+    """fp32: against the float64 operator.  bf16 (HP_PRECISION_BF16): operands that already lie on the bf16
+    grid are not changed by the kernel's rounding and their products are exact in fp32, so the same float64
+    operator is the expected value up to fp32 accumulation order -- any indexing slip in the bf16 fragment
+    layout or the transposing LDS reads shows as an O(1) error.  bf16x3 / bf16x6 take arbitrary fp32
+    operands: 2 planes keep 16 significant bits (tolerance 3e-5), 3 planes all 24 (held to the fp32 bar)."""
     import ctypes as C
 
     from hiddenpose_amd import _lib
 
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
     B, D, H, W = dims
     x = torch.randn(B, cin, D, H, W, generator=g)
     w = torch.randn((cin, cout, k, k, k) if tr else (cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3 / s ** 3)
+    if precision == "bf16":
+        x, w = _bf16_grid(x), _bf16_grid(w)
     xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
     ref = F.conv_transpose3d(xd, wd, stride=s, padding=p) if tr else F.conv3d(xd, wd, stride=s, padding=p)
     gy = torch.randn(ref.shape, generator=g)
+    if precision == "bf16":
+        gy = _bf16_grid(gy)
     (ref * gy.double()).sum().backward()
 
     L = _lib.lib()
     xc = cl(x).cuda()
     wc = w.cuda()
-    desc = ops._desc(xc, cout, k, s, p, tr)
+    prev = ops.set_conv_precision(precision)
+    try:
+        desc = ops._desc(xc, cout, k, s, p, tr)
+    finally:
+        ops.set_conv_precision(prev)
+    assert desc.precision == {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}[precision]
+    tol_f, tol_g = (3e-5, 3e-5) if precision == "bf16x3" else (2e-6, 5e-6)
     st = ops._stream(xc)
     wf, _ = ops._pack(desc, wc, True, False)
     do, ho, wo = ops._out_dims(desc)
@@ -60,13 +80,13 @@ def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims):
     y = torch.empty(B, do, ho, wo, cout, device="cuda")
     stats = torch.empty(2 * cout, dtype=torch.float64, device="cuda")
     _lib.check(L.hp_conv3d_forward(C.byref(desc), xc.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st), "fwd")
-    assert rel_l2(ncdhw(y), ref) < 2e-6
+    assert rel_l2(ncdhw(y), ref) < tol_f
     refcl = cl(ref.detach())
-    assert rel_l2(stats[:cout], refcl.reshape(-1, cout).sum(0)) < 1e-5
-    assert rel_l2(stats[cout:], (refcl.reshape(-1, cout) ** 2).sum(0)) < 1e-5
+    assert rel_l2(stats[:cout], refcl.reshape(-1, cout).sum(0)) < 10 * tol_f
+    assert rel_l2(stats[cout:], (refcl.reshape(-1, cout) ** 2).sum(0)) < 10 * tol_f
     dx, dw = ops._conv_grads(desc, xc, wc, cl(gy).cuda(), True)
-    assert rel_l2(ncdhw(dx), xd.grad) < 5e-6
-    assert rel_l2(dw, wd.grad) < 5e-6
+    assert rel_l2(ncdhw(dx), xd.grad) < tol_g
+    assert rel_l2(dw, wd.grad) < tol_g
 
 
 @pytest.mark.parametrize("train,relu,with_res", [(True, True, True), (True, True, False), (False, True, True), (True, False, False)])

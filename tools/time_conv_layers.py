@@ -12,6 +12,7 @@ from hiddenpose_amd import hip_ops as ops
 L = _lib.lib()
 T, N, B = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (128, 128, 4)))
 which = sys.argv[4] if len(sys.argv) > 4 else "fwd,dgrad,wgrad"
+ops.set_conv_precision(sys.argv[5] if len(sys.argv) > 5 else "fp32")
 
 
 def layers():
@@ -47,7 +48,7 @@ def timeit(fn, reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-print(f"T={T} N={N} B={B}")
+print(f"T={T} N={N} B={B} precision={ops.get_conv_precision()}")
 for name, cin, cout, k, s, p, tr, d in layers():
     x = torch.randn(B, *d, cin, device="cuda")
     w = torch.randn((cin, cout, k, k, k) if tr else (cout, cin, k, k, k), device="cuda") * 0.05
@@ -66,7 +67,7 @@ for name, cin, cout, k, s, p, tr, d in layers():
         t = timeit(lambda: L.hp_conv3d_forward(C.byref(desc), x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), None, st))
         res.append(f"fwd {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
     if "dgrad" in which:
-        t = timeit(lambda: L.hp_conv3d_backward_data(C.byref(desc), gy.data_ptr(), wd.data_ptr(), dx.data_ptr(), st))
+        t = timeit(lambda: L.hp_conv3d_backward_data(C.byref(desc), gy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, st))
         res.append(f"dgrad {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
     if "wgrad" in which:
         t = timeit(lambda: L.hp_conv3d_backward_weight(C.byref(desc), x.data_ptr(), gy.data_ptr(), dwp.data_ptr(), st))
