@@ -80,6 +80,10 @@ SIGNATURES = {
     "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),
     "hp_sformer_qkv_prepare": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_float, _fp, _fp, _i, _vp]),
     "hp_sformer_attention_workspace_bytes": (_sz, [_i, _i, _i]),
+    "hp_rgbe_decode": (_i, [_vp, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _sz]),
+    "hp_ingest_rgbe_to_meas": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
+    "hp_box_downsample_round": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),
+    "hp_pair_average_axis0": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),
     "hp_sformer_attention": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 

@@ -48,6 +48,8 @@ def _compile(src: str, force: bool) -> str:
     cmd = [HIPCC] + COMMON
     if src.endswith(".cpp"):
         cmd += ["-ffp-contract=off", "-x", "hip"]  # host-only float32 constants must not be FMA-contracted
+    elif "HP_BUILD: -ffp-contract=off" in open(src).read(2048):
+        cmd += ["-ffp-contract=off"]  # kernels that reproduce NumPy float32 arithmetic bit for bit
     cmd += ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

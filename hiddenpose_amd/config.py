@@ -71,7 +71,8 @@ def get_cfg_defaults() -> CfgNode:
         # "bf16" (bf16 operands / fp32 accumulation; LCT, U-Net, norms and losses stay fp32)
         CONV_PRECISION="fp32",
     )
-    c.DATASET = CfgNode(NAME="NlosPoseDataset", NUM_JOINTS=24, HEATMAP_SIZE=[64, 64, 64], DAWNSAMPLE_CNT=1)
+    c.DATASET = CfgNode(NAME="NlosPoseDataset", NUM_JOINTS=24, HEATMAP_SIZE=[64, 64, 64], VOL_SIZE=[256, 256, 256],
+                        DAWNSAMPLE_CNT=1, PHASE="train", TRAIN_PATH="", TEST_PATH="")
     c.TRAIN = CfgNode(OPTIMIZER="adam", LR=0.001, LR_FACTOR=0.2, LR_STEP=[2, 4, 13], BATCH_SIZE=2,
                       BEGIN_EPOCH=0, END_EPOCH=15)
     c.TEST = CfgNode(TYPE="pose_v2", BATCH_SIZE=2)

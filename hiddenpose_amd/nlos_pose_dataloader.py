@@ -1,0 +1,127 @@
+"""Drop-in for the reference's utils/nlos_pose_dataloader.py:20-148 (`NlosPoseDataset`) with the per-sample
+arithmetic on the GPU: the CPU worker only reads files (and expands the .hdr run-length container with the
+library's host routine); decode, both normalisations, gray conversion, crop and the averaging pyramid run in
+csrc/ingest_kernels.hip through the C ABI (hp_rgbe_decode, hp_ingest_rgbe_to_meas, hp_box_downsample_round).
+
+`__getitem__` returns what the reference returns -- (meas (1,T,H,W), vol (1,D,H,W), joints (24,3), person_id) --
+except that meas and vol are fp32 tensors on `device` instead of NumPy arrays.  Error behaviour follows
+:72-104: a sample whose file cannot be read or whose maximum is below 1e-10 is replaced by sample 0 (the
+reference also swaps the joints but keeps the failing sample's volume; so does this class).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import _lib
+
+FRAMES, KEEP_FRAMES = 600, 512  # rearrange '(t h) w -> t h w', t=600 and [:512]  (:107)
+
+
+def decode_hdr(path: str) -> np.ndarray:
+    """Radiance file -> (rows, W, 4) uint8 RGBE on the host (file parsing only; hp_rgbe_decode)."""
+    L = _lib.lib()
+    raw = np.fromfile(path, dtype=np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    _lib.check(L.hp_rgbe_decode(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), None, 0), "hp_rgbe_decode")
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    _lib.check(L.hp_rgbe_decode(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), out.ctypes.data, out.nbytes), "hp_rgbe_decode")
+    return out
+
+
+def rgbe_to_meas(rgbe: torch.Tensor, downsample_cnt: int, frames: int = FRAMES, keep: int = KEEP_FRAMES) -> torch.Tensor:
+    """(frames*H, W, 4) uint8 device tensor -> (keep/2^(cnt+1), H/2^cnt, W/2^cnt) fp32 (:74-83, :107-117)."""
+    if not rgbe.is_cuda:
+        raise _lib.HiddenPoseHipError("rgbe_to_meas needs a HIP device tensor (no CPU path)")
+    rows, W, four = rgbe.shape
+    assert four == 4 and rgbe.dtype == torch.uint8 and rows % frames == 0
+    H = rows // frames
+    div = 1 << downsample_cnt
+    meas = torch.empty(keep // (2 * div), H // div, W // div, dtype=torch.float32, device=rgbe.device)
+    maxima = torch.empty(2, dtype=torch.float32, device=rgbe.device)
+    rgbe = rgbe.contiguous()
+    st = torch.cuda.current_stream(rgbe.device).cuda_stream
+    _lib.check(_lib.lib().hp_ingest_rgbe_to_meas(rgbe.data_ptr(), frames, H, W, keep, downsample_cnt, meas.data_ptr(),
+                                                 maxima.data_ptr(), st), "hp_ingest_rgbe_to_meas")
+    if abs(float(maxima[0])) < 1e-10:  # :75 (one 4-byte read-back per sample)
+        raise ValueError("wrong Meas File!")
+    return meas
+
+
+def box_pyramid(v: torch.Tensor, rounds: int) -> torch.Tensor:
+    """:114-121: `rounds` times pair averages along each of the three axes of a (D,H,W) fp32 device tensor."""
+    if not v.is_cuda:
+        raise _lib.HiddenPoseHipError("box_pyramid needs a HIP device tensor (no CPU path)")
+    L = _lib.lib()
+    st = torch.cuda.current_stream(v.device).cuda_stream
+    for _ in range(rounds):
+        D, H, W = v.shape
+        out = torch.empty(D // 2, H // 2, W // 2, dtype=torch.float32, device=v.device)
+        _lib.check(L.hp_box_downsample_round(v.data_ptr(), out.data_ptr(), D, H, W, *v.stride(), st), "hp_box_downsample_round")
+        v = out
+    return v
+
+
+def remap_joints(joints: np.ndarray, vol_size: int, heatmap_size: int) -> np.ndarray:
+    """:128-143: metres -> 256^3 voxels, (x,y,z) -> (d,h,w), then to heat-map voxels.  24x3 values: host."""
+    j = np.asarray(joints, dtype=np.float64)
+    w = j[:, 0] * 128 + 128
+    h = 256 - (j[:, 1] * 128 + 128)
+    d = 225 - (j[:, 2] * 128 + 128)
+    return np.stack([d, h, w], axis=1) / (vol_size / heatmap_size)
+
+
+class NlosPoseDataset(Dataset):
+    def __init__(self, cfg, datapath, device=None):
+        super().__init__()
+        self.vol_size = cfg.DATASET.VOL_SIZE
+        self.heatmap_size = cfg.MODEL.HEATMAP_SIZE
+        self.downsample_cnt = cfg.DATASET.DAWNSAMPLE_CNT
+        self.phase = cfg.DATASET.PHASE
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.measFiles, self.volFiles, self.jointsFiles, self.wrongMeasFiles = [], [], [], []
+        for pose in os.listdir(datapath):
+            for split in os.listdir(os.path.join(datapath, pose)):
+                if self.phase not in split:
+                    continue
+                base = os.path.join(datapath, pose, split)
+                for name in os.listdir(os.path.join(base, "meas")):
+                    stem, ext = os.path.splitext(name)
+                    assert ext == ".hdr", f"Data type should be .hdr,not {name} in {os.path.join(base, 'meas')}"
+                    vol = os.path.join(base, "vol", stem + ".mat")
+                    joints = os.path.join(base, "joints", stem + ".joints")
+                    assert os.path.isfile(vol), f"Do not have related vol {vol}"
+                    assert os.path.isfile(joints), f"Do not have related joints {joints}"
+                    self.measFiles.append(os.path.join(base, "meas", name))
+                    self.volFiles.append(vol)
+                    self.jointsFiles.append(joints)
+        for kind, files in (("meas", self.measFiles), ("vol", self.volFiles), ("joints", self.jointsFiles)):
+            print(f"total {self.phase} {kind} is {len(files)}")
+
+    def _meas(self, path):
+        rgbe = torch.from_numpy(decode_hdr(path)).to(self.device, non_blocking=True)
+        return rgbe_to_meas(rgbe, self.downsample_cnt)
+
+    def __getitem__(self, index):
+        from scipy.io import loadmat
+
+        meas_file, joint_file = self.measFiles[index], self.jointsFiles[index]
+        try:
+            meas = self._meas(meas_file)
+        except Exception:  # :84-104: any failure falls back to sample 0 (meas and joints, not the volume)
+            print(f"--------------------\nNo.{index} {meas_file} meas is wrong. \n--------------------------\n")
+            self.wrongMeasFiles.append(meas_file)
+            meas_file, joint_file = self.measFiles[0], self.jointsFiles[0]
+            meas = self._meas(meas_file)
+        vol = torch.from_numpy(loadmat(self.volFiles[index])["vol"].astype(np.float32)).to(self.device)
+        vol = box_pyramid(vol, self.downsample_cnt)
+        joints = remap_joints(np.loadtxt(joint_file), self.vol_size[0], self.heatmap_size[0])
+        person_id = os.path.splitext(os.path.basename(meas_file))[0]
+        return meas[None], vol[None], joints, person_id
+
+    def __len__(self):
+        return len(self.volFiles)

@@ -118,3 +118,24 @@ def mpjpe(pred: torch.Tensor, ref: torch.Tensor, num_joints: int = 24) -> float:
     p = pred.reshape(pred.shape[0], num_joints, 3).double()
     r = ref.reshape(ref.shape[0], num_joints, 3).double()
     return (p - r).norm(dim=2).mean().item()
+
+
+def synthetic_rgbe(frames: int, H: int, W: int, seed: int = 0):
+    """Seeded (frames*H, W, 4) uint8 Radiance RGBE pixels shaped like a transient histogram image: most pixels
+    dark (exponent 0 or small), a band of bright returns; runs of equal bytes so that RLE has work to do."""
+    import numpy as np
+
+    g = np.random.Generator(np.random.PCG64(seed))
+    img = np.zeros((frames * H, W, 4), np.uint8)
+    mant = g.integers(0, 256, size=(frames * H, W, 3), dtype=np.uint8)
+    expo = g.integers(118, 131, size=(frames * H, W), dtype=np.uint8)
+    dark = g.random((frames * H, W)) < 0.35
+    expo[dark] = 0
+    mant[dark] = 0
+    # horizontal runs: repeat every 4th column block in a third of the rows
+    rows = g.random(frames * H) < 0.33
+    mant[rows, 1::2] = mant[rows, 0::2][:, : mant[rows, 1::2].shape[1]]
+    expo[rows, 1::2] = expo[rows, 0::2][:, : expo[rows, 1::2].shape[1]]
+    img[..., :3] = mant
+    img[..., 3] = expo
+    return img

@@ -255,6 +255,34 @@ int hp_sformer_attention(const float* Q, const float* K, const float* K0, const 
                          int dh, int Ntok,
                          int num_joints, int patches_per_frame, int frames, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Measurement ingest (utils/nlos_pose_dataloader.py:71-144, utils/loadrealdata.py:6-15): the per-sample
+ * CPU work of the reference's Dataset.__getitem__, moved to the device.
+ * ---------------------------------------------------------------------- */
+/* HOST function: Radiance .hdr container (what cv2.imread(file, -1) parses at :74) -> flat R,G,B,E bytes,
+ * row-major (height, width, 4).  Header "#?...", "FORMAT=32-bit_rle_rgbe", blank line, "-Y H +X W";
+ * scanlines either new-style run-length encoded (2, 2, W_hi, W_lo prefix) or flat.  Call with rgbe = NULL
+ * to query width/height.  No device is touched. */
+int hp_rgbe_decode(const unsigned char* file, size_t nbytes, int* width, int* height, unsigned char* rgbe,
+                   size_t rgbe_capacity);
+/* DEVICE: flat RGBE image of `frames` stacked (H, W) frames -> normalised gray transient volume:
+ *   float BGR = mantissa * 2^(e-136); / max; gray = 0.114 B + 0.587 G + 0.299 R; / max    (:74-83)
+ *   'reshape (frames H) W -> frames H W', keep the first keep_frames                        (:107)
+ *   (m[::2] + m[1::2]) / 2 along time, then downsample_cnt rounds of t, h, w pair averages (:113-117)
+ * meas: (keep_frames / 2^(cnt+1), H / 2^cnt, W / 2^cnt) fp32.  maxima: 2 floats of device scratch that
+ * receive the two global maxima (the caller may read maxima[0] to apply the reference's
+ * 'abs(meas.max()) < 1e-10 -> wrong Meas File' rule at :75). */
+int hp_ingest_rgbe_to_meas(const unsigned char* rgbe, int frames, int H, int W, int keep_frames, int downsample_cnt,
+                           float* meas, float* maxima, void* stream);
+/* One round of the reference's box pyramid on a float volume addressed by element strides:
+ * out[d,h,w] = pair averages along d, then h, then w (each (a+b)/2), contiguous (D/2, H/2, W/2)  (:114-121) */
+int hp_box_downsample_round(const float* in, float* out, int D, int H, int W, long stride_d, long stride_h,
+                            long stride_w, void* stream);
+/* (m[::2] + m[1::2]) / 2 along the leading axis of a strided volume -> contiguous (D/2, H, W).  With the
+ * strides of 'h w t -> t w h' this is loadrealdata.py:9-10 without materialising the rearranged array. */
+int hp_pair_average_axis0(const float* in, float* out, int D, int H, int W, long stride_d, long stride_h, long stride_w,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

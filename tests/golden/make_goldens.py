@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax   (default: all)
+Sections: ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax   (default: all)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
 its filler keyed by state_dict name, so tests rebuild identical inputs and
@@ -337,7 +337,61 @@ def sec_schema():
           f"{sum(int(np.prod(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k)} parameters")
 
 
-SECTIONS = {"sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
+def sec_ingest():
+    """utils/loadrealdata.py:6-15 and NlosPoseDataset.__getitem__ (utils/nlos_pose_dataloader.py:71-144).
+    cv2 is absent from this image: imread / cvtColor are the oracle's restatement of OpenCV's RGBE reader and
+    float BGR2GRAY, so ingest_getitem.npz pins every other line of __getitem__ (see oracle/ingest_oracle.py)."""
+    import tempfile
+
+    from scipy.io import savemat
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import ingest_oracle as io
+
+    from utils.loadrealdata import load_realdata
+
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        g = np.random.Generator(np.random.PCG64(5))
+        for tag, dt, cnt in (("f32", np.float32, 1), ("f64", np.float64, 2)):
+            data = g.random((8, 12, 32)).astype(dt)  # (h, w, t)
+            path = os.path.join(tmp, f"real_{tag}.mat")
+            savemat(path, {"data_new": data})
+            y = load_realdata(path, downsample_cnt=cnt)
+            out[f"real_{tag}_in"] = data
+            out[f"real_{tag}_out"] = y.numpy()
+            out[f"real_{tag}_cnt"] = cnt
+            print(f"  load_realdata {tag}: {data.shape} -> {tuple(y.shape)} {y.dtype}")
+        save("ingest_realdata.npz", **out)
+
+        # dataset tree: <root>/<pose>/<phase>/{meas,vol,joints}/<id>.{hdr,mat,joints}
+        cv2 = sys.modules["cv2"]
+        cv2.imread = lambda path, flag: io.rgbe_to_bgr_float(io.rgbe_read(open(path, "rb").read()))
+        cv2.cvtColor = lambda img, code: io.bgr2gray_f32(img)
+        cv2.COLOR_BGR2GRAY = 6
+        from utils.nlos_pose_dataloader import NlosPoseDataset
+
+        H = W = 8
+        root = os.path.join(tmp, "data")
+        for sub in ("meas", "vol", "joints"):
+            os.makedirs(os.path.join(root, "pose0", "train", sub))
+        rgbe = hpt.synthetic_rgbe(600, H, W, seed=7)
+        open(os.path.join(root, "pose0", "train", "meas", "person_3.hdr"), "wb").write(io.rgbe_write(rgbe, rle=True))
+        vol = (g.random((8, 8, 8)) < 0.3).astype(np.float64)
+        savemat(os.path.join(root, "pose0", "train", "vol", "person_3.mat"), {"vol": vol})
+        joints = g.random((24, 3)) - 0.5
+        np.savetxt(os.path.join(root, "pose0", "train", "joints", "person_3.joints"), joints)
+        cfg = ref_shims._AttrDict()
+        cfg.DATASET = ref_shims._AttrDict(VOL_SIZE=[256, 256, 256], DAWNSAMPLE_CNT=1, PHASE="train")
+        cfg.MODEL = ref_shims._AttrDict(HEATMAP_SIZE=[64, 64, 64])
+        ds = NlosPoseDataset(cfg, root)
+        meas, v, j, pid = ds[0]
+        print(f"  __getitem__: meas {meas.shape} {meas.dtype}, vol {v.shape} {v.dtype}, joints {j.shape}, id {pid}")
+        save("ingest_getitem.npz", vol_in=vol, joints_in=np.loadtxt(os.path.join(root, "pose0", "train", "joints", "person_3.joints")),
+             meas=meas, vol=v, joints=j, person_id=np.array(pid))
+
+
+SECTIONS = {"ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax}
 
 if __name__ == "__main__":
