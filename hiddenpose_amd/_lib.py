@@ -56,7 +56,8 @@ SIGNATURES = {
     "hp_dconv3_forward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hp_dconv3_backward_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "hp_dconv3_backward_data": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "hp_dconv3_backward_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_dconv3_backward_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "hp_dconv3_backward_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_groupnorm_workspace_bytes": (_sz, [_i, _i]),
     "hp_groupnorm_relu_forward": (_i, [_fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, C.c_float, _fp, _fp, _vp, _vp]),
     "hp_groupnorm_relu_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),

@@ -198,10 +198,47 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
   const int ntaps = STEM ? 1 : class_ntaps(g, cls);
   const int KT = ntaps * g.kpt;
 
+  // Gather addressing without per-tile index arithmetic: element offset = rowoff[i] (this thread's voxel and
+  // channel quad, fixed) + a wave-uniform tap offset; whether tap t falls inside the volume for row i is decided
+  // once, as bit t of vmask[i] (<= 64 taps per class), and shifted out one bit per tap.
+  long rowoff[4], wrow[BN / 32];
+  unsigned long long vmask[4];
+  bool wvalid[BN / 32];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rowoff[i] = ((((long)rb[i] * g.Di + rz[i]) * g.Hi + ry[i]) * g.Wi + rx[i]) * g.Cin + kq * 4;
+    vmask[i] = 0ull;
+  }
+  if constexpr (!STEM) {
+    for (int t = ntaps - 1; t >= 0; --t) {
+      int dz, dy, dx, widx;
+      tap_info(g, cls, t, dz, dy, dx, widx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = rv[i] && (unsigned)(rz[i] + dz) < (unsigned)g.Di && (unsigned)(ry[i] + dy) < (unsigned)g.Hi &&
+                        (unsigned)(rx[i] + dx) < (unsigned)g.Wi;
+        vmask[i] = (vmask[i] << 1) | (ok ? 1ull : 0ull);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    wvalid[i] = n < g.Nout;
+    wrow[i] = (long)n * g.Cin + kq * 4;
+  }
+
   float4 ra[4], rbw[BN / 32];
   // running (tap, channel tile) of the NEXT tile to gather: no division in the K loop
-  int ld_tap = 0, ld_ci = 0, ld_dz = 0, ld_dy = 0, ld_dx = 0, ld_widx = 0;
-  if (!STEM) tap_info(g, cls, 0, ld_dz, ld_dy, ld_dx, ld_widx);
+  int ld_tap = 0, ld_ci = 0;
+  long ld_xoff = 0, ld_woff = 0;  // wave-uniform: tap displacement in X, tap slab in the packed weights
+  auto tap_offsets = [&](int t) {
+    int dz, dy, dx, widx;
+    tap_info(g, cls, t, dz, dy, dx, widx);
+    ld_xoff = (((long)dz * g.Hi + dy) * g.Wi + dx) * g.Cin;
+    ld_woff = (long)widx * g.Nout * g.Cin;
+  };
+  if (!STEM) tap_offsets(0);
   auto load_tile = [&](int kt) {
     if constexpr (STEM) {
       // single input channel, 7^3 taps spread along K: element (row, kk) = x[voxel + off(kk)]
@@ -226,25 +263,21 @@ __global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const
         rbw[i] = n < g.Nout ? *(const float4*)(Wp + (long)n * (g.kpt * BK) + kbase) : make_float4(0, 0, 0, 0);
       }
     } else {
-      const int c0 = ld_ci * BK + kq * 4;
-      const int dz = ld_dz, dy = ld_dy, dx = ld_dx, widx = ld_widx;
+      const int cofs = ld_ci * BK;
+      const bool cok = cofs + kq * 4 < g.Cin;
+      const float* const xb = X + (ld_xoff + cofs);
+      const float* const wb = Wp + (ld_woff + cofs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int z = rz[i] + dz, y = ry[i] + dy, x = rx[i] + dx;
-        const bool ok = rv[i] && c0 < g.Cin && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi &&
-                        (unsigned)x < (unsigned)g.Wi;
-        ra[i] = ok ? *(const float4*)(X + (long)(unsigned)(((rb[i] * g.Di + z) * g.Hi + y) * g.Wi + x) * g.Cin + c0)
-                   : make_float4(0, 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i)
+        ra[i] = (cok && (vmask[i] & 1ull)) ? *(const float4*)(xb + rowoff[i]) : make_float4(0, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < BN / 32; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        rbw[i] = (n < g.Nout && c0 < g.Cin) ? *(const float4*)(Wp + ((long)widx * g.Nout + n) * g.Cin + c0)
-                                            : make_float4(0, 0, 0, 0);
-      }
+      for (int i = 0; i < BN / 32; ++i)
+        rbw[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i]) : make_float4(0, 0, 0, 0);
       if (++ld_ci == g.kpt) {
         ld_ci = 0;
-        if (++ld_tap < ntaps) tap_info(g, cls, ld_tap, ld_dz, ld_dy, ld_dx, ld_widx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vmask[i] >>= 1;
+        if (++ld_tap < ntaps) tap_offsets(ld_tap);
       }
     }
   };

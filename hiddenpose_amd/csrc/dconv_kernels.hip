@@ -222,6 +222,188 @@ __global__ __launch_bounds__(DT) void k_dconv3_wgrad(const float* __restrict__ x
   }
 }
 
+
+// Weight gradient on the matrix cores, for any channel count: v_mfma_f32_4x4x1_16b_f32 computes 16 independent
+// 4x4 outer products per instruction (64 FLOP/clk/SIMD, twice the VALU FMA rate, exact fp32).  Block b of the
+// 16 = voxel x + b of a 16-voxel x-run; row i = output channel co0 + i, column j = input channel ci0 + j:
+//     D_b[i][j] += g[co0+i][v_b] * x[ci0+j][v_b + tap]
+// so lane 4b+i supplies g, lane 4b+j supplies the shifted x, and each lane keeps D_b[.][j] (4 registers) per
+// tap: 27 taps x 4 = 108 accumulators (+4 for the bias gradient: the same product with x = 1).
+// A workgroup owns an 8 (y) x 64 (x) column of one (batch, 4 co, 4 ci) task and slides along z; the padded x
+// planes live in a 4-slot LDS ring (plane z+2 is fetched while plane z is multiplied: one barrier per plane).
+// Every shifted operand is ONE ds_read_b32 with a compile-time offset (row pitch 68: the 64 lanes of a read
+// fall on every bank exactly twice, the minimum for 256 bytes); g comes straight from global memory, one load
+// per 27 MFMAs.  At the end the 16 blocks are summed with shuffles, the 4 waves combine in LDS and the
+// workgroup issues one atomic per weight (all workgroups add into the same few hundred floats, so the number
+// of atomic packets has to stay small).
+constexpr int WG_TY = 8, WG_TX = 64, WG_PX = 68, WG_PY = WG_TY + 2, WG_PLANE = 4 * WG_PY * WG_PX;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int PADMODE>
+__global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g,
+                                                           int cin, int cout,
+                                                           int D, int H, int W, int tiles_x, int tiles_y, int zchunk,
+                                                           int cig_n, float* __restrict__ partial) {
+  __shared__ float ring[4 * WG_PLANE];
+  __shared__ float part[4][28 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = lane >> 2, sub = lane & 3;
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y;
+  const int cig = blockIdx.z % cig_n, cog = blockIdx.z / cig_n;
+  const int x0 = bx * WG_TX, y0 = by * WG_TY;
+  const int zb = bz * zchunk, ze = min(D, zb + zchunk);
+  const int co = cog * 4 + sub;
+  const bool co_ok = co < cout;
+  const long cs = (long)D * H * W;
+  const float* gch = g + ((long)b * cout + (co_ok ? co : 0)) * cs;
+  const float* xb = x + ((long)b * cin + cig * 4) * cs;
+  const bool want_db = cig == 0;
+
+  // Staging map, fixed for the whole z walk: element e = tid + 256 k of the [4 ch][10 rows][68 cols] plane image
+  // (the LDS offset IS e) comes from offset soff[k] inside the channel-0 z-plane, or is zero when bit k of smask
+  // is clear (zero padding, columns 66/67, channels past cin).
+  constexpr int SK = (WG_PLANE + 255) / 256;
+  int soff[SK];
+  unsigned smask = 0;
+#pragma unroll
+  for (int k = 0; k < SK; ++k) {
+    const int e = tid + 256 * k;
+    const int c = e / (WG_PY * WG_PX);
+    const int r = e - c * (WG_PY * WG_PX);
+    const int ly = r / WG_PX, lx = r - ly * WG_PX;
+    int yy = y0 + ly - 1, xx = x0 + lx - 1;
+    bool ok = e < WG_PLANE && lx < 66 && cig * 4 + c < cin;
+    if (PADMODE == 1) {
+      yy = min(max(yy, 0), H - 1);
+      xx = min(max(xx, 0), W - 1);
+    } else {
+      ok = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    }
+    soff[k] = ok ? (int)((long)c * cs + (long)yy * W + xx) : 0;
+    smask |= ok ? (1u << k) : 0u;
+  }
+  auto stage = [&](int zp) {
+    float* dst = ring + (zp & 3) * WG_PLANE + tid;
+    int zz = zp;
+    bool zok = (unsigned)zz < (unsigned)D;
+    if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
+    const float* src = xb + (long)zz * H * W;
+    float v[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+#pragma unroll
+    for (int k = 0; k < SK; ++k)
+      if (tid + 256 * k < WG_PLANE) dst[256 * k] = v[k];
+  };
+
+  f32x4 acc[28];
+#pragma unroll
+  for (int t = 0; t < 28; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (zb < ze) {
+    stage(zb - 1);
+    stage(zb);
+    stage(zb + 1);
+  }
+  __syncthreads();
+  // this lane's offset inside a plane for row r, run q: (sub * PY + (2*wave + r) + dy) * PX + q*16 + blk + dx
+  const int lbase = (sub * WG_PY + 2 * wave) * WG_PX + blk;
+  for (int z = zb; z < ze; ++z) {
+    if (z + 1 < ze) stage(z + 2);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
+    const float* p0 = ring + ((z - 1) & 3) * WG_PLANE + lbase;
+    const float* p1 = ring + (z & 3) * WG_PLANE + lbase;
+    const float* p2 = ring + ((z + 1) & 3) * WG_PLANE + lbase;
+    // 8 (row, run) pairs per plane, one g value each; the next pair's g is in flight while this one multiplies
+    auto g_at = [&](int rq) -> float {
+      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
+      return (co_ok && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
+    };
+    float gnext = g_at(0);
+#pragma unroll 1
+    for (int rq = 0; rq < 8; ++rq) {
+      const float gv = gnext;
+      if (rq + 1 < 8) gnext = g_at(rq + 1);
+      const int off = (rq >> 2) * WG_PX + (rq & 3) * 16;
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const float* pl = (dz == 0 ? p0 : dz == 1 ? p1 : p2) + off;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            acc[(dz * 3 + dy) * 3 + dx] =
+                __builtin_amdgcn_mfma_f32_4x4x1f32(gv, pl[dy * WG_PX + dx], acc[(dz * 3 + dy) * 3 + dx], 0, 0, 0);
+      }
+      if (want_db) acc[27] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, 1.0f, acc[27], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // sum the 16 blocks: lanes with equal (lane & 3) hold the same (., j) column of different voxels
+#pragma unroll
+  for (int t = 0; t < 28; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[t][i];
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[t][i] = v;
+    }
+  if (blk == 0) {
+#pragma unroll
+    for (int t = 0; t < 28; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave][(i * 4 + sub) * 28 + t] = acc[t][i];  // [co i][ci j][tap]
+  }
+  __syncthreads();
+  // partial[pair][workgroup of the pair][448]: plain stores, summed by k_dconv3_wgrad_reduce in a fixed order
+  const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long)gridDim.x * gridDim.y;
+  float* out = partial + ((long)blockIdx.z * nwg + wg) * (16 * 28);
+  for (int u = tid; u < 16 * 28; u += 256) out[u] = part[0][u] + part[1][u] + part[2][u] + part[3][u];
+}
+
+// dw[co][ci][tap] / db[co] = sum over the workgroups of the (co group, ci group) pair, in a fixed order:
+// grid (pair, 7 column chunks of 64); 1024 threads = 16 slices of the workgroup range x 64 columns.
+__global__ __launch_bounds__(1024) void k_dconv3_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw,
+                                                              float* __restrict__ db, int cin, int cout, int cig_n, long nwg) {
+  __shared__ float red[16][64];
+  const int pair = blockIdx.x, cig = pair % cig_n, cog = pair / cig_n;
+  const int slice = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = blockIdx.y * 64 + lane;
+  const float* src = partial + (long)pair * nwg * (16 * 28) + u;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long w = slice;
+  for (; w + 48 < nwg; w += 64) {
+    s0 += src[w * (16 * 28)];
+    s1 += src[(w + 16) * (16 * 28)];
+    s2 += src[(w + 32) * (16 * 28)];
+    s3 += src[(w + 48) * (16 * 28)];
+  }
+  for (; w < nwg; w += 16) s0 += src[w * (16 * 28)];
+  red[slice][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][lane];
+    const int t = u % 28, j = (u / 28) & 3, i = u / (28 * 4);
+    const int oc = cog * 4 + i, ic = cig * 4 + j;
+    if (oc < cout) {
+      if (t < 27) {
+        if (ic < cin) dw[((long)oc * cin + ic) * 27 + t] = v;
+      } else if (db && cig == 0 && j == 0) {
+        db[oc] = v;
+      }
+    }
+  }
+}
+
 template <int COUT, int VX>
 static void launch_dconv(int padmode, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias,
                          float* y, int cin, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
@@ -303,22 +485,50 @@ extern "C" int hp_dconv3_backward_data(const float* gy, const float* w, float* g
   return HP_OK;
 }
 
+namespace {
+struct WgradGeom {
+  int cog_n, cig_n, tiles_x, tiles_y, zsplit, zchunk;
+  long nwg;  // workgroups per channel pair
+};
+WgradGeom wgrad_geom(int B, int cin, int cout, int D, int H, int W) {
+  WgradGeom q;
+  q.cog_n = (cout + 3) / 4;
+  q.cig_n = (cin + 3) / 4;
+  q.tiles_x = (W + hp::WG_TX - 1) / hp::WG_TX;
+  q.tiles_y = (H + hp::WG_TY - 1) / hp::WG_TY;
+  // z range per workgroup: ~1024 workgroups (2 resident per CU), at least 8 planes each: 2 halo planes are
+  // re-read and one 448-value reduction is paid per chunk
+  const long cols = (long)q.tiles_x * q.tiles_y * B * q.cog_n * q.cig_n;
+  q.zsplit = (int)std::max<long>(1, std::min<long>((D + 7) / 8, (1024 + cols - 1) / cols));
+  q.zchunk = (D + q.zsplit - 1) / q.zsplit;
+  q.zsplit = (D + q.zchunk - 1) / q.zchunk;
+  q.nwg = (long)q.tiles_x * q.tiles_y * q.zsplit * B;
+  return q;
+}
+}  // namespace
+
+extern "C" size_t hp_dconv3_backward_weight_workspace_bytes(int B, int cin, int cout, int D, int H, int W) {
+  if (B < 1 || cin < 1 || cout < 1 || D < 1 || H < 1 || W < 1) return 0;
+  const WgradGeom q = wgrad_geom(B, cin, cout, D, H, W);
+  return sizeof(float) * (size_t)q.cog_n * q.cig_n * q.nwg * 16 * 28;
+}
+
 extern "C" int hp_dconv3_backward_weight(const float* x, const float* gy, float* dw, float* dbias, int B, int cin,
-                                         int cout, int D, int H, int W, int replicate_pad, void* stream) {
-  HP_REQUIRE(x && gy && dw && B > 0, "hp_dconv3_backward_weight: bad argument");
+                                         int cout, int D, int H, int W, int replicate_pad, void* workspace, void* stream) {
+  HP_REQUIRE(x && gy && dw && workspace && B > 0, "hp_dconv3_backward_weight: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  HP_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cout * cin * 27, st));
-  if (dbias) HP_CHECK_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * cout, st));
-  const int tiles_x = (W + WTX - 1) / WTX, tiles_y = (H + TY - 1) / TY, tiles_z = (D + TZ - 1) / TZ;
-  const int co_chunks = (cout + WCO - 1) / WCO, ci_chunks = (cin + CC - 1) / CC;
-  dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B, (unsigned)(co_chunks * ci_chunks));
+  const WgradGeom q = wgrad_geom(B, cin, cout, D, H, W);
+  dim3 grid((unsigned)(q.tiles_x * q.tiles_y * q.zsplit), (unsigned)B, (unsigned)(q.cog_n * q.cig_n));
+  float* partial = (float*)workspace;
   HP_PROF("dconv3_wgrad", st);
   if (replicate_pad)
-    hipLaunchKernelGGL((k_dconv3_wgrad<1>), grid, dim3(DT), 0, st, x, gy, dw, dbias, cin, cout, D, H, W, tiles_x, tiles_y,
-                       co_chunks, ci_chunks);
+    hipLaunchKernelGGL((k_dconv3_wgrad_mfma<1>), grid, dim3(256), 0, st, x, gy, cin, cout, D, H, W, q.tiles_x, q.tiles_y,
+                       q.zchunk, q.cig_n, partial);
   else
-    hipLaunchKernelGGL((k_dconv3_wgrad<0>), grid, dim3(DT), 0, st, x, gy, dw, dbias, cin, cout, D, H, W, tiles_x, tiles_y,
-                       co_chunks, ci_chunks);
+    hipLaunchKernelGGL((k_dconv3_wgrad_mfma<0>), grid, dim3(256), 0, st, x, gy, cin, cout, D, H, W, q.tiles_x, q.tiles_y,
+                       q.zchunk, q.cig_n, partial);
+  hipLaunchKernelGGL(k_dconv3_wgrad_reduce, dim3((unsigned)(q.cog_n * q.cig_n), 7), dim3(1024), 0, st, partial, dw, dbias, cin, cout,
+                     q.cig_n, q.nwg);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

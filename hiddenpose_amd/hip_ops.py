@@ -73,8 +73,10 @@ class _DConv3(torch.autograd.Function):
                                                      _lib.ptr(ws), st), "hp_dconv3_backward_data")
             dw = torch.empty_like(w)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+            nbw = int(L.hp_dconv3_backward_weight_workspace_bytes(b, cin, cout, d, h, wd))
+            wsw = torch.empty(nbw // 4, dtype=torch.float32, device=x.device)
             _lib.check(L.hp_dconv3_backward_weight(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
-                                                   d, h, wd, rp, st), "hp_dconv3_backward_weight")
+                                                   d, h, wd, rp, wsw.data_ptr(), st), "hp_dconv3_backward_weight")
         return gx, dw, db, None
 
 

@@ -174,9 +174,12 @@ int hp_dconv3_forward(const float* x, const float* w, const float* bias, float* 
 size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad);
 int hp_dconv3_backward_data(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H, int W,
                             int replicate_pad, void* workspace, void* stream);
-/* dw (Cout,Cin,3,3,3) and dbias (Cout, may be NULL) are zeroed and accumulated by the call. */
+/* dw (Cout,Cin,3,3,3) and dbias (Cout, may be NULL) are overwritten.  workspace (device, sized by the query)
+ * holds per-workgroup partial sums that a second kernel adds in a fixed order: no atomics, run-to-run
+ * bit-identical. */
+size_t hp_dconv3_backward_weight_workspace_bytes(int B, int cin, int cout, int D, int H, int W);
 int hp_dconv3_backward_weight(const float* x, const float* gy, float* dw, float* dbias, int B, int cin, int cout, int D,
-                              int H, int W, int replicate_pad, void* stream);
+                              int H, int W, int replicate_pad, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------
  * UNet3d memory-bound stages (unet/unet3d.py), planar (B, C, D, H, W) fp32; V = D*H*W.

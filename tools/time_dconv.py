@@ -15,6 +15,7 @@ for (cin, cout, rep, dims) in [(1,1,1,(2,128,128,128)), (1,4,0,(2,128,128,128)),
         torch.cuda.synchronize(); return (time.perf_counter()-t0)/5*1e3
     a=t(lambda: L.hp_dconv3_forward(x.data_ptr(),w.data_ptr(),None,y.data_ptr(),B,cin,cout,D,H,W,rep,st))
     b=t(lambda: L.hp_dconv3_backward_data(g.data_ptr(),w.data_ptr(),gx.data_ptr(),B,cin,cout,D,H,W,rep,ws.data_ptr(),st))
-    c=t(lambda: L.hp_dconv3_backward_weight(x.data_ptr(),g.data_ptr(),dw.data_ptr(),db.data_ptr(),B,cin,cout,D,H,W,rep,st))
+    wsw = torch.empty(int(L.hp_dconv3_backward_weight_workspace_bytes(B,cin,cout,D,H,W))//4, device='cuda')
+    c=t(lambda: L.hp_dconv3_backward_weight(x.data_ptr(),g.data_ptr(),dw.data_ptr(),db.data_ptr(),B,cin,cout,D,H,W,rep,wsw.data_ptr(),st))
     gf=2*B*D*H*W*27*cin*cout/1e9; gb=(cin+cout)*B*D*H*W*4/1e9
     print(f"{cin}->{cout} rep{rep} {dims}: fwd {a:.3f} ms ({gf/a:.0f} GF/s, {gb/a*1e3:.0f} GB/s) dgrad {b:.3f} wgrad {c:.3f} ms ({gf/c:.0f} GF/s)")
