@@ -404,6 +404,139 @@ __global__ __launch_bounds__(1024) void k_dconv3_wgrad_reduce(const float* __res
   }
 }
 
+
+// Forward / data-gradient 3x3x3 convolution on the same 4x4x1 matrix-core instruction.  Roles: row i = output
+// channel co0 + i (lane 4b+i supplies the weight, identical in all 16 blocks), column j = voxel 4b + j of a 64-voxel
+// x-run (lane l supplies x[l + tap]), K = one (input channel, tap) per instruction:
+//     D_b[i][j] += w[co0+i][ci][tap] * x[ci][v_{4b+j} + tap]        -> lane l keeps out[co0 .. co0+3][v_l]
+// A workgroup owns an 8 (y) x 64 (x) output column of one (batch, 4 co) task and slides along z with the input
+// planes of a 4-channel chunk in the same 4-slot LDS ring as the weight gradient; the 27 weights of the current
+// input channel sit in registers (7 broadcast ds_read_b128 per channel and plane).  More than 4 input channels:
+// the chunks are separate z sweeps and every sweep after the first adds into y.
+template <int PADMODE>
+__global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int cin,
+                                                         int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad,
+                                                         long wsco, long wsci, int flip, int tiles_x, int tiles_y, int zchunk) {
+  __shared__ float ring[4 * WG_PLANE];
+  __shared__ __attribute__((aligned(16))) float wl[4 * 4 * 28];  // [ci][co][28]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 3;
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y, cog = blockIdx.z;
+  const int x0 = bx * WG_TX, y0 = by * WG_TY;
+  const int zb = bz * zchunk, ze = min(Do, zb + zchunk);
+  const long ics = (long)Di * Hi * Wi, ocs = (long)Do * Ho * Wo;
+  constexpr int SK = (WG_PLANE + 255) / 256;
+
+  for (int c0 = 0; c0 < cin; c0 += 4) {
+    const int nci = min(4, cin - c0);
+    const float* xb = x + ((long)b * cin + c0) * ics;
+    __syncthreads();  // previous sweep: ring and weight image are free
+    // weights of this (4 co, 4 ci) pair: wl[ci][co][tap]
+    for (int e = tid; e < 4 * 4 * 28; e += 256) {
+      const int tap = e % 28, co = (e / 28) & 3, ci = e / (28 * 4);
+      float v = 0.f;
+      if (tap < 27 && cog * 4 + co < cout && ci < nci)
+        v = w[(long)(cog * 4 + co) * wsco + (long)(c0 + ci) * wsci + (flip ? 26 - tap : tap)];
+      wl[e] = v;
+    }
+    // staging map (see the weight-gradient kernel): element e = tid + 256 k of the [4][10][68] plane image
+    int soff[SK];
+    unsigned smask = 0;
+#pragma unroll
+    for (int k = 0; k < SK; ++k) {
+      const int e = tid + 256 * k;
+      const int c = e / (WG_PY * WG_PX);
+      const int r = e - c * (WG_PY * WG_PX);
+      const int ly = r / WG_PX, lx = r - ly * WG_PX;
+      int yy = y0 + ly - pad, xx = x0 + lx - pad;
+      bool ok = e < WG_PLANE && lx < 66 && c < nci;
+      if (PADMODE == 1) {
+        yy = min(max(yy, 0), Hi - 1);
+        xx = min(max(xx, 0), Wi - 1);
+      } else {
+        ok = ok && (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
+      }
+      soff[k] = ok ? (int)((long)c * ics + (long)yy * Wi + xx) : 0;
+      smask |= ok ? (1u << k) : 0u;
+    }
+    auto stage = [&](int zin) {  // input plane zin (any integer) -> ring slot zin & 3
+      float* dst = ring + (zin & 3) * WG_PLANE + tid;
+      int zz = zin;
+      bool zok = (unsigned)zz < (unsigned)Di;
+      if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
+      const float* src = xb + (long)zz * Hi * Wi;
+      float v[SK];
+#pragma unroll
+      for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+#pragma unroll
+      for (int k = 0; k < SK; ++k)
+        if (tid + 256 * k < WG_PLANE) dst[256 * k] = v[k];
+    };
+    if (zb < ze) {
+      stage(zb - pad);
+      stage(zb - pad + 1);
+      stage(zb - pad + 2);
+    }
+    __syncthreads();
+    const int lbase = (2 * wave) * WG_PX + lane;
+    for (int z = zb; z < ze; ++z) {
+      if (z + 1 < ze) stage(z - pad + 3);  // the slot it replaces held plane z - pad - 1, last read one barrier ago
+      const float* p0 = ring + ((z - pad) & 3) * WG_PLANE + lbase;
+      const float* p1 = ring + ((z - pad + 1) & 3) * WG_PLANE + lbase;
+      const float* p2 = ring + ((z - pad + 2) & 3) * WG_PLANE + lbase;
+      f32x4 acc[2];
+      acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ci = 0; ci < nci; ++ci) {
+        float wr[28];
+        const f32x4* wp = (const f32x4*)(wl + (ci * 4 + sub) * 28);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const f32x4 t4 = wp[q];
+          wr[4 * q] = t4[0];
+          wr[4 * q + 1] = t4[1];
+          wr[4 * q + 2] = t4[2];
+          wr[4 * q + 3] = t4[3];
+        }
+        const int co_ = ci * WG_PY * WG_PX;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz) {
+            const float* pl = (dz == 0 ? p0 : dz == 1 ? p1 : p2) + co_ + r * WG_PX;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx)
+                acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[(dz * 3 + dy) * 3 + dx], pl[dy * WG_PX + dx], acc[r], 0, 0, 0);
+          }
+      }
+      // lane l holds out[co0 + i][row][x0 + l] in acc[row][i]
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = y0 + 2 * wave + r, ox = x0 + lane;
+        if (oy < Ho && ox < Wo) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int oc = cog * 4 + i;
+            if (oc < cout) {
+              float* yp = y + ((long)b * cout + oc) * ocs + ((long)z * Ho + oy) * Wo + ox;
+              *yp = acc[r][i] + (c0 == 0 ? (bias ? bias[oc] : 0.f) : *yp);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int COUT, int VX>
 static void launch_dconv(int padmode, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias,
                          float* y, int cin, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
@@ -422,26 +555,18 @@ static int vx_for(int cout) { return cout <= 8 ? 4 : 2; }
 static int run_dconv(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int Di, int Hi,
                      int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci, int flip, int padmode,
                      hipStream_t st) {
-  const int VX = vx_for(cout), TX = 8 * VX;
-  const int tiles_x = (Wo + TX - 1) / TX, tiles_y = (Ho + TY - 1) / TY, tiles_z = (Do + TZ - 1) / TZ;
-  dim3 grid((unsigned)(tiles_x * tiles_y * tiles_z), (unsigned)B);
-#define HP_DCONV_CASE(CO, V)                                                                                      \
-  case CO:                                                                                                        \
-    launch_dconv<CO, V>(padmode, grid, st, x, w, bias, y, cin, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, wsci, flip, tiles_x, \
-                        tiles_y);                                                                                 \
-    break;
-  switch (cout) {
-    HP_DCONV_CASE(1, 4)
-    HP_DCONV_CASE(4, 4)
-    HP_DCONV_CASE(8, 4)
-    HP_DCONV_CASE(16, 2)
-    HP_DCONV_CASE(32, 2)
-    HP_DCONV_CASE(64, 2)
-    default:
-      set_error("direct conv: unsupported output channel count %d (1,4,8,16,32,64)", cout);
-      return HP_ERR_UNSUPPORTED;
-  }
-#undef HP_DCONV_CASE
+  const int tiles_x = (Wo + WG_TX - 1) / WG_TX, tiles_y = (Ho + WG_TY - 1) / WG_TY, cog_n = (cout + 3) / 4;
+  const long cols = (long)tiles_x * tiles_y * B * cog_n;
+  int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (1536 + cols - 1) / cols));
+  const int zchunk = (Do + zsplit - 1) / zsplit;
+  zsplit = (Do + zchunk - 1) / zchunk;
+  dim3 grid((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)B, (unsigned)cog_n);
+  if (padmode)
+    hipLaunchKernelGGL((k_dconv3_mfma<1>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
+                       wsci, flip, tiles_x, tiles_y, zchunk);
+  else
+    hipLaunchKernelGGL((k_dconv3_mfma<0>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
+                       wsci, flip, tiles_x, tiles_y, zchunk);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
