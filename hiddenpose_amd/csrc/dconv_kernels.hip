@@ -1,111 +1,22 @@
 // Direct 3x3x3 convolutions for the thin-channel stages (FeatureExtraction: 1 channel;
 // UNet3d: 4..64 channels), planar fp32 (B, C, D, H, W) as in the reference.
 //
-// These layers are bandwidth / VALU work, not matrix work: with 4..32 output channels an
-// MFMA tile would be mostly padding, and the fp32 MFMA rate equals the fp32 VALU rate on
-// gfx950 anyway.  So: one thread owns VX consecutive x voxels and ALL output channels; the
-// input tile with its halo is staged in LDS once per 4-channel chunk; weights are wave
-// uniform and come through the scalar cache; every LDS value feeds 3*COUT FMAs.
+// With 1..64 channels a 32x32 MFMA tile would be mostly padding, but gfx950 also has
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products per instruction, exact fp32, 64 FLOP/clk/SIMD
+// (twice the VALU FMA rate) -- a 4-channel x 4-channel (or 4-channel x 4-voxel) block is exactly this
+// layer family's shape.  All three directions use it, with the input planes of a 4-channel chunk held in
+// a 4-slot LDS ring while the workgroup slides along z:
 //
 //   forward     y = conv(x, w) + bias                 zero or replicate padding
 //   data grad   the same kernel with swapped channel strides and flipped taps
 //               (replicate padding: "full" correlation on the +1 halo domain, then a fold)
-//   weight grad one thread per (co, ci, dz, dy) row of 3 taps, sliding along x in LDS
+//   weight grad 16 voxels x (4 co x 4 ci) per instruction, atomic-free two-stage reduction
 #include <algorithm>
 
 #include "hp_internal.h"
 
 namespace hp {
 
-constexpr int DT = 256;
-constexpr int TZ = 4, TY = 8, CC = 4;  // tile depth/height, input-channel chunk
-
-template <int COUT, int VX, int PADMODE>
-__global__ __launch_bounds__(DT) void k_dconv3(const float* __restrict__ x, const float* __restrict__ w,
-                                               const float* __restrict__ bias, float* __restrict__ y, int cin, int Di,
-                                               int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
-                                               int flip, int tiles_x, int tiles_y) {
-  constexpr int TX = 8 * VX;
-  constexpr int LZ = TZ + 2, LY = TY + 2, LX = TX + 2, LVOL = LZ * LY * LX;
-  __shared__ float xs[CC * LVOL];
-  const int tid = threadIdx.x;
-  const int txg = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
-  int t = blockIdx.x;
-  const int bx = t % tiles_x;
-  t /= tiles_x;
-  const int by = t % tiles_y;
-  const int bz = t / tiles_y;
-  const int b = blockIdx.y;
-  const int oz0 = bz * TZ, oy0 = by * TY, ox0 = bx * TX;
-  const long in_cs = (long)Di * Hi * Wi;
-
-  float acc[COUT][VX];
-#pragma unroll
-  for (int co = 0; co < COUT; ++co)
-#pragma unroll
-    for (int v = 0; v < VX; ++v) acc[co][v] = 0.f;
-
-  for (int c0 = 0; c0 < cin; c0 += CC) {
-    __syncthreads();
-    for (int i = tid; i < CC * LVOL; i += DT) {
-      const int c = i / LVOL;
-      int r = i - c * LVOL;
-      const int lz = r / (LY * LX);
-      r -= lz * (LY * LX);
-      const int ly = r / LX, lx = r - ly * LX;
-      int gz = oz0 + lz - pad, gy = oy0 + ly - pad, gx = ox0 + lx - pad;
-      float v = 0.f;
-      if (c0 + c < cin) {
-        if (PADMODE == 1) {
-          gz = min(max(gz, 0), Di - 1);
-          gy = min(max(gy, 0), Hi - 1);
-          gx = min(max(gx, 0), Wi - 1);
-          v = x[((long)b * cin + c0 + c) * in_cs + ((long)gz * Hi + gy) * Wi + gx];
-        } else if ((unsigned)gz < (unsigned)Di && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi) {
-          v = x[((long)b * cin + c0 + c) * in_cs + ((long)gz * Hi + gy) * Wi + gx];
-        }
-      }
-      xs[i] = v;
-    }
-    __syncthreads();
-    const int cn = min(CC, cin - c0);
-    for (int c = 0; c < cn; ++c) {
-      const float* wc = w + (long)(c0 + c) * wsci;
-#pragma unroll
-      for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const float* row = xs + c * LVOL + ((tz + dz) * LY + (ty + dy)) * LX + txg * VX;
-          float r[VX + 2];
-#pragma unroll
-          for (int j = 0; j < VX + 2; ++j) r[j] = row[j];
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int tap = (dz * 3 + dy) * 3 + dx;
-            const int ti = flip ? 26 - tap : tap;
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-              const float wv = wc[(long)co * wsco + ti];
-#pragma unroll
-              for (int v = 0; v < VX; ++v) acc[co][v] = fmaf(r[v + dx], wv, acc[co][v]);
-            }
-          }
-        }
-    }
-  }
-  const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + txg * VX;
-  if (oz < Do && oy < Ho) {
-    const long out_cs = (long)Do * Ho * Wo;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      const float bv = bias ? bias[co] : 0.f;
-      float* yp = y + ((long)b * COUT + co) * out_cs + ((long)oz * Ho + oy) * Wo + ox;
-#pragma unroll
-      for (int v = 0; v < VX; ++v)
-        if (ox + v < Wo) yp[v] = acc[co][v] + bv;
-    }
-  }
-}
 
 // adjoint of replicate padding by 1: dx[p] = sum of the halo-domain cells that clamp to p
 __global__ void k_fold_replicate(const float* __restrict__ dpad, float* __restrict__ dx, long nvol, int D, int H, int W) {
@@ -128,100 +39,6 @@ __global__ void k_fold_replicate(const float* __restrict__ dpad, float* __restri
     dx[i] = s;
   }
 }
-
-// Weight gradient: dW[co][ci][tap] += sum_v g[co][v] * x[ci][v + tap - 1],  db[co] += sum_v g[co][v].
-// Block = one voxel tile (4 x 8 x 32) x one (8 co, 4 ci) channel chunk; thread = one
-// (co, ci, dz, dy) row, sliding a 3-wide window along x so each FMA costs 2/3 LDS read.
-constexpr int WCO = 8, WTX = 32;
-template <int PADMODE>
-__global__ __launch_bounds__(DT) void k_dconv3_wgrad(const float* __restrict__ x, const float* __restrict__ g,
-                                                     float* __restrict__ dw, float* __restrict__ db, int cin, int cout,
-                                                     int D, int H, int W, int tiles_x, int tiles_y, int co_chunks,
-                                                     int ci_chunks) {
-  constexpr int LZ = TZ + 2, LY = TY + 2, LX = WTX + 2, LVOL = LZ * LY * LX;
-  constexpr int GV = TZ * TY * WTX, GLD = GV + 1;
-  __shared__ float xs[CC * LVOL];
-  __shared__ float gs[WCO * GLD];
-  const int tid = threadIdx.x;
-  int t = blockIdx.x;
-  const int bx = t % tiles_x;
-  t /= tiles_x;
-  const int by = t % tiles_y;
-  const int bz = t / tiles_y;
-  const int b = blockIdx.y;
-  const int cic = blockIdx.z % ci_chunks, coc = blockIdx.z / ci_chunks;
-  (void)co_chunks;
-  const int co0 = coc * WCO, ci0 = cic * CC;
-  const int z0 = bz * TZ, y0 = by * TY, x0 = bx * WTX;
-  const long cs = (long)D * H * W;
-  for (int i = tid; i < CC * LVOL; i += DT) {
-    const int c = i / LVOL;
-    int r = i - c * LVOL;
-    const int lz = r / (LY * LX);
-    r -= lz * (LY * LX);
-    const int ly = r / LX, lx = r - ly * LX;
-    int gz = z0 + lz - 1, gy = y0 + ly - 1, gx = x0 + lx - 1;
-    float v = 0.f;
-    if (ci0 + c < cin) {
-      if (PADMODE == 1) {
-        gz = min(max(gz, 0), D - 1);
-        gy = min(max(gy, 0), H - 1);
-        gx = min(max(gx, 0), W - 1);
-        v = x[((long)b * cin + ci0 + c) * cs + ((long)gz * H + gy) * W + gx];
-      } else if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-        v = x[((long)b * cin + ci0 + c) * cs + ((long)gz * H + gy) * W + gx];
-      }
-    }
-    xs[i] = v;
-  }
-  for (int i = tid; i < WCO * GV; i += DT) {
-    const int c = i / GV;
-    int r = i - c * GV;
-    const int lz = r / (TY * WTX);
-    r -= lz * (TY * WTX);
-    const int ly = r / WTX, lx = r - ly * WTX;
-    const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
-    float v = 0.f;
-    if (co0 + c < cout && gz < D && gy < H && gx < W) v = g[((long)b * cout + co0 + c) * cs + ((long)gz * H + gy) * W + gx];
-    gs[c * GLD + (i - c * GV)] = v;
-  }
-  __syncthreads();
-  // rows: (co, ci, dz, dy) -> 8 * 4 * 9 = 288 rows over 256 threads
-  for (int row = tid; row < WCO * CC * 9; row += DT) {
-    const int dy = row % 3, dz = (row / 3) % 3, ci = (row / 9) % CC, co = row / (9 * CC);
-    if (co0 + co >= cout || ci0 + ci >= cin) continue;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const float* gp = gs + co * GLD;
-    const float* xp = xs + ci * LVOL;
-    for (int z = 0; z < TZ; ++z)
-      for (int yy = 0; yy < TY; ++yy) {
-        const float* xr = xp + ((z + dz) * LY + (yy + dy)) * LX;
-        const float* gr = gp + (z * TY + yy) * WTX;
-        float w0 = xr[0], w1 = xr[1];
-#pragma unroll 8
-        for (int xx = 0; xx < WTX; ++xx) {
-          const float w2 = xr[xx + 2];
-          const float gv = gr[xx];
-          a0 = fmaf(gv, w0, a0);
-          a1 = fmaf(gv, w1, a1);
-          a2 = fmaf(gv, w2, a2);
-          w0 = w1;
-          w1 = w2;
-        }
-      }
-    float* o = dw + ((long)(co0 + co) * cin + ci0 + ci) * 27 + (dz * 3 + dy) * 3;
-    atomicAdd(o + 0, a0);
-    atomicAdd(o + 1, a1);
-    atomicAdd(o + 2, a2);
-  }
-  if (db && cic == 0 && tid < WCO && co0 + tid < cout) {
-    float s = 0.f;
-    const float* gp = gs + tid * GLD;
-    for (int i = 0; i < GV; ++i) s += gp[i];
-    atomicAdd(db + co0 + tid, s);
-  }
-}
-
 
 // Weight gradient on the matrix cores, for any channel count: v_mfma_f32_4x4x1_16b_f32 computes 16 independent
 // 4x4 outer products per instruction (64 FLOP/clk/SIMD, twice the VALU FMA rate, exact fp32).  Block b of the
@@ -363,6 +180,140 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   }
   __syncthreads();
   // partial[pair][workgroup of the pair][448]: plain stores, summed by k_dconv3_wgrad_reduce in a fixed order
+  const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long)gridDim.x * gridDim.y;
+  float* out = partial + ((long)blockIdx.z * nwg + wg) * (16 * 28);
+  for (int u = tid; u < 16 * 28; u += 256) out[u] = part[0][u] + part[1][u] + part[2][u] + part[3][u];
+}
+
+
+// Single input channel (FeatureExtraction, first U-Net conv): the 4 columns of the outer product would be 3/4
+// padding, so they carry four TAPS instead -- column j of step m is tap 4m + j, 7 instructions cover the 27 taps:
+//     D_b[i][j] += g[co0+i][v_b] * x[0][v_b + tap(4m+j)]
+// Same ring (one channel per plane image), same partial layout ([co][ci = 0][tap]) and reduction kernel.
+constexpr int W1_PLANE = WG_PY * WG_PX;
+template <int PADMODE>
+__global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 int cout, int D, int H, int W, int tiles_x, int tiles_y,
+                                                                 int zchunk, float* __restrict__ partial) {
+  __shared__ float ring[4 * W1_PLANE];
+  __shared__ float part[4][28 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = lane >> 2, sub = lane & 3;
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y, cog = blockIdx.z;
+  const int x0 = bx * WG_TX, y0 = by * WG_TY;
+  const int zb = bz * zchunk, ze = min(D, zb + zchunk);
+  const int co = cog * 4 + sub;
+  const bool co_ok = co < cout;
+  const long cs = (long)D * H * W;
+  const float* gch = g + ((long)b * cout + (co_ok ? co : 0)) * cs;
+  const float* xb = x + (long)b * cs;
+  for (int u = tid; u < 4 * 28 * 16; u += 256) (&part[0][0])[u] = 0.f;
+
+  constexpr int SK = (W1_PLANE + 255) / 256;
+  int soff[SK];
+  unsigned smask = 0;
+#pragma unroll
+  for (int k = 0; k < SK; ++k) {
+    const int e = tid + 256 * k;
+    const int ly = e / WG_PX, lx = e - ly * WG_PX;
+    int yy = y0 + ly - 1, xx = x0 + lx - 1;
+    bool ok = e < W1_PLANE && lx < 66;
+    if (PADMODE == 1) {
+      yy = min(max(yy, 0), H - 1);
+      xx = min(max(xx, 0), W - 1);
+    } else {
+      ok = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    }
+    soff[k] = ok ? (int)((long)yy * W + xx) : 0;
+    smask |= ok ? (1u << k) : 0u;
+  }
+  auto stage = [&](int zp) {
+    float* dst = ring + (zp & 3) * W1_PLANE + tid;
+    int zz = zp;
+    bool zok = (unsigned)zz < (unsigned)D;
+    if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
+    const float* src = xb + (long)zz * H * W;
+    float v[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+#pragma unroll
+    for (int k = 0; k < SK; ++k)
+      if (tid + 256 * k < W1_PLANE) dst[256 * k] = v[k];
+  };
+  // this lane's tap of step m: t = 4m + sub -> (dz, in-plane offset); t = 27 does not exist (operand forced to 0)
+  int tdz[7], toff[7];
+#pragma unroll
+  for (int m = 0; m < 7; ++m) {
+    const int t = min(4 * m + sub, 26);
+    tdz[m] = t / 9;
+    toff[m] = ((t / 3) % 3) * WG_PX + t % 3;
+  }
+  const bool last_ok = sub != 3;  // tap 27
+
+  f32x4 acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (zb < ze) {
+    stage(zb - 1);
+    stage(zb);
+    stage(zb + 1);
+  }
+  __syncthreads();
+  const int lbase = (2 * wave) * WG_PX + blk;
+  for (int z = zb; z < ze; ++z) {
+    if (z + 1 < ze) stage(z + 2);
+    const float* pm[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) pm[m] = ring + ((z - 1 + tdz[m]) & 3) * W1_PLANE + lbase + toff[m];
+    auto g_at = [&](int rq) -> float {
+      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
+      return (co_ok && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
+    };
+    float gnext = g_at(0);
+#pragma unroll 1
+    for (int rq = 0; rq < 8; ++rq) {
+      const float gv = gnext;
+      if (rq + 1 < 8) gnext = g_at(rq + 1);
+      const int off = (rq >> 2) * WG_PX + (rq & 3) * 16;
+#pragma unroll
+      for (int m = 0; m < 7; ++m) {
+        float xv = pm[m][off];
+        if (m == 6) xv = last_ok ? xv : 0.f;
+        acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, xv, acc[m], 0, 0, 0);
+      }
+      acc[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, 1.0f, acc[7], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[m][i];
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[m][i] = v;
+    }
+  if (blk == 0) {
+#pragma unroll
+    for (int m = 0; m < 7; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * m + sub < 27) part[wave][(i * 4) * 28 + 4 * m + sub] = acc[m][i];  // [co i][ci 0][tap]
+    if (sub == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave][(i * 4) * 28 + 27] = acc[7][i];
+    }
+  }
+  __syncthreads();
   const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long)gridDim.x * gridDim.y;
   float* out = partial + ((long)blockIdx.z * nwg + wg) * (16 * 28);
   for (int u = tid; u < 16 * 28; u += 256) out[u] = part[0][u] + part[1][u] + part[2][u] + part[3][u];
@@ -537,20 +488,6 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
   }
 }
 
-template <int COUT, int VX>
-static void launch_dconv(int padmode, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias,
-                         float* y, int cin, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
-                         int flip, int tiles_x, int tiles_y) {
-  if (padmode)
-    hipLaunchKernelGGL((k_dconv3<COUT, VX, 1>), grid, dim3(DT), 0, st, x, w, bias, y, cin, Di, Hi, Wi, Do, Ho, Wo, pad,
-                       wsco, wsci, flip, tiles_x, tiles_y);
-  else
-    hipLaunchKernelGGL((k_dconv3<COUT, VX, 0>), grid, dim3(DT), 0, st, x, w, bias, y, cin, Di, Hi, Wi, Do, Ho, Wo, pad,
-                       wsco, wsci, flip, tiles_x, tiles_y);
-}
-
-static int vx_for(int cout) { return cout <= 8 ? 4 : 2; }
-
 // generic entry: y (B,cout,Do,Ho,Wo) = conv3(x (B,cin,Di,Hi,Wi)) with weight(co,ci,tap) = w[co*wsco + ci*wsci + tap']
 static int run_dconv(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int Di, int Hi,
                      int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci, int flip, int padmode,
@@ -646,12 +583,20 @@ extern "C" int hp_dconv3_backward_weight(const float* x, const float* gy, float*
   dim3 grid((unsigned)(q.tiles_x * q.tiles_y * q.zsplit), (unsigned)B, (unsigned)(q.cog_n * q.cig_n));
   float* partial = (float*)workspace;
   HP_PROF("dconv3_wgrad", st);
-  if (replicate_pad)
+  if (cin == 1) {
+    if (replicate_pad)
+      hipLaunchKernelGGL((k_dconv3_wgrad_mfma_c1<1>), grid, dim3(256), 0, st, x, gy, cout, D, H, W, q.tiles_x, q.tiles_y, q.zchunk,
+                         partial);
+    else
+      hipLaunchKernelGGL((k_dconv3_wgrad_mfma_c1<0>), grid, dim3(256), 0, st, x, gy, cout, D, H, W, q.tiles_x, q.tiles_y, q.zchunk,
+                         partial);
+  } else if (replicate_pad) {
     hipLaunchKernelGGL((k_dconv3_wgrad_mfma<1>), grid, dim3(256), 0, st, x, gy, cin, cout, D, H, W, q.tiles_x, q.tiles_y,
                        q.zchunk, q.cig_n, partial);
-  else
+  } else {
     hipLaunchKernelGGL((k_dconv3_wgrad_mfma<0>), grid, dim3(256), 0, st, x, gy, cin, cout, D, H, W, q.tiles_x, q.tiles_y,
                        q.zchunk, q.cig_n, partial);
+  }
   hipLaunchKernelGGL(k_dconv3_wgrad_reduce, dim3((unsigned)(q.cog_n * q.cig_n), 7), dim3(1024), 0, st, partial, dw, dbias, cin, cout,
                      q.cig_n, q.nwg);
   HP_CHECK_HIP(hipGetLastError());
