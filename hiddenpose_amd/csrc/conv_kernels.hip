@@ -159,7 +159,7 @@ struct TileCfg {
 };
 
 template <int BN, bool STEM, bool STATS, int NP>
-__global__ __launch_bounds__(CT) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
+__global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, float* __restrict__ Y,
                                               double* __restrict__ stats, const float* __restrict__ addend,
                                               IgemmGeom g) {
