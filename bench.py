@@ -158,7 +158,7 @@ def bench_sformer(args):
     print(json.dumps({
         "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.conv_precision if bf16 else "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"NlosPoseSformer forward, batch {B}, 16 frames x 128x128, patch 4, dim 256, depth 8, "
                                "8 heads x 32, random-init weights"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},
