@@ -104,18 +104,26 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
     soff[k] = ok ? (int)((long)c * cs + (long)yy * W + xx) : 0;
     smask |= ok ? (1u << k) : 0u;
   }
-  auto stage = [&](int zp) {
-    float* dst = ring + (zp & 3) * WG_PLANE + tid;
+  // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
+  // (stage_store) after it, so the global-memory latency hides behind the MFMAs
+  auto stage_load = [&](int zp, float (&v)[SK]) {
     int zz = zp;
     bool zok = (unsigned)zz < (unsigned)D;
     if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
     const float* src = xb + (long)zz * H * W;
-    float v[SK];
 #pragma unroll
     for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+  };
+  auto stage_store = [&](int zp, const float (&v)[SK]) {
+    float* dst = ring + (zp & 3) * WG_PLANE + tid;
 #pragma unroll
     for (int k = 0; k < SK; ++k)
       if (tid + 256 * k < WG_PLANE) dst[256 * k] = v[k];
+  };
+  auto stage = [&](int zp) {
+    float v[SK];
+    stage_load(zp, v);
+    stage_store(zp, v);
   };
 
   f32x4 acc[28];
@@ -131,7 +139,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   // this lane's offset inside a plane for row r, run q: (sub * PY + (2*wave + r) + dy) * PX + q*16 + blk + dx
   const int lbase = (sub * WG_PY + 2 * wave) * WG_PX + blk;
   for (int z = zb; z < ze; ++z) {
-    if (z + 1 < ze) stage(z + 2);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
+    float nxt[SK];
+    if (z + 1 < ze) stage_load(z + 2, nxt);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
     const float* p0 = ring + ((z - 1) & 3) * WG_PLANE + lbase;
     const float* p1 = ring + (z & 3) * WG_PLANE + lbase;
     const float* p2 = ring + ((z + 1) & 3) * WG_PLANE + lbase;
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
       }
       if (want_db) acc[27] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, 1.0f, acc[27], 0, 0, 0);
     }
+    if (z + 1 < ze) stage_store(z + 2, nxt);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
     __syncthreads();
   }
   // sum the 16 blocks: lanes with equal (lane & 3) hold the same (., j) column of different voxels
@@ -232,18 +243,26 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
     soff[k] = ok ? (int)((long)yy * W + xx) : 0;
     smask |= ok ? (1u << k) : 0u;
   }
-  auto stage = [&](int zp) {
-    float* dst = ring + (zp & 3) * W1_PLANE + tid;
+  // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
+  // (stage_store) after it, so the global-memory latency hides behind the MFMAs
+  auto stage_load = [&](int zp, float (&v)[SK]) {
     int zz = zp;
     bool zok = (unsigned)zz < (unsigned)D;
     if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
     const float* src = xb + (long)zz * H * W;
-    float v[SK];
 #pragma unroll
     for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+  };
+  auto stage_store = [&](int zp, const float (&v)[SK]) {
+    float* dst = ring + (zp & 3) * W1_PLANE + tid;
 #pragma unroll
     for (int k = 0; k < SK; ++k)
       if (tid + 256 * k < W1_PLANE) dst[256 * k] = v[k];
+  };
+  auto stage = [&](int zp) {
+    float v[SK];
+    stage_load(zp, v);
+    stage_store(zp, v);
   };
   // this lane's tap of step m: t = 4m + sub -> (dz, in-plane offset); t = 27 does not exist (operand forced to 0)
   int tdz[7], toff[7];
@@ -267,7 +286,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   __syncthreads();
   const int lbase = (2 * wave) * WG_PX + blk;
   for (int z = zb; z < ze; ++z) {
-    if (z + 1 < ze) stage(z + 2);
+    float nxt[SK];
+    if (z + 1 < ze) stage_load(z + 2, nxt);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
     const float* pm[7];
 #pragma unroll
     for (int m = 0; m < 7; ++m) pm[m] = ring + ((z - 1 + tdz[m]) & 3) * W1_PLANE + lbase + toff[m];
@@ -289,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
       }
       acc[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, 1.0f, acc[7], 0, 0, 0);
     }
+    if (z + 1 < ze) stage_store(z + 2, nxt);
     __syncthreads();
   }
 #pragma unroll
@@ -416,18 +438,26 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
       soff[k] = ok ? (int)((long)c * ics + (long)yy * Wi + xx) : 0;
       smask |= ok ? (1u << k) : 0u;
     }
-    auto stage = [&](int zin) {  // input plane zin (any integer) -> ring slot zin & 3
-      float* dst = ring + (zin & 3) * WG_PLANE + tid;
+    // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
+    // (stage_store) after it, so the global-memory latency hides behind the MFMAs
+    auto stage_load = [&](int zin, float (&v)[SK]) {
       int zz = zin;
       bool zok = (unsigned)zz < (unsigned)Di;
       if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
       const float* src = xb + (long)zz * Hi * Wi;
-      float v[SK];
 #pragma unroll
       for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+    };
+    auto stage_store = [&](int zin, const float (&v)[SK]) {
+      float* dst = ring + (zin & 3) * WG_PLANE + tid;
 #pragma unroll
       for (int k = 0; k < SK; ++k)
         if (tid + 256 * k < WG_PLANE) dst[256 * k] = v[k];
+    };
+    auto stage = [&](int zin) {
+      float v[SK];
+      stage_load(zin, v);
+      stage_store(zin, v);
     };
     if (zb < ze) {
       stage(zb - pad);
@@ -437,7 +467,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     __syncthreads();
     const int lbase = (2 * wave) * WG_PX + lane;
     for (int z = zb; z < ze; ++z) {
-      if (z + 1 < ze) stage(z - pad + 3);  // the slot it replaces held plane z - pad - 1, last read one barrier ago
+      float nxt[SK];
+      if (z + 1 < ze) stage_load(z - pad + 3, nxt);
+      __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
       const float* p0 = ring + ((z - pad) & 3) * WG_PLANE + lbase;
       const float* p1 = ring + ((z - pad + 1) & 3) * WG_PLANE + lbase;
       const float* p2 = ring + ((z - pad + 2) & 3) * WG_PLANE + lbase;
@@ -483,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
           }
         }
       }
+      if (z + 1 < ze) stage_store(z - pad + 3, nxt);  // the slot held plane z - pad - 1, last read one barrier ago
       __syncthreads();
     }
   }
