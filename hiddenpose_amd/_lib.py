@@ -81,6 +81,7 @@ SIGNATURES = {
     "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),
     "hp_sformer_qkv_prepare": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_float, _fp, _fp, _i, _vp]),
     "hp_sformer_attention_workspace_bytes": (_sz, [_i, _i, _i]),
+    "hp_lct_time_window": (_i, [_fp, _fp, _i, _i, _i, _i, C.c_long, C.POINTER(C.c_int), _i, _vp]),
     "hp_rgbe_decode": (_i, [_vp, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _sz]),
     "hp_ingest_rgbe_to_meas": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "hp_box_downsample_round": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),

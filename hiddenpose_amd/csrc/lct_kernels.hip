@@ -677,3 +677,22 @@ extern "C" int hp_lct_plan_get_invpsf(const hp_lct_plan* p, float* re, float* im
       }
   return HP_OK;
 }
+
+extern "C" int hp_lct_time_window(float* y_full, float* x_window, int B, int D, int tnum, int T, long plane, const int* tbes,
+                                  int to_window, void* stream) {
+  HP_REQUIRE(y_full && x_window && tbes && B >= 1 && D >= 1 && tnum >= 1 && tnum <= T && plane >= 1,
+             "hp_lct_time_window: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t row = sizeof(float) * (size_t)tnum * plane, full = sizeof(float) * (size_t)T * plane;
+  if (!to_window) HP_CHECK_HIP(hipMemsetAsync(y_full, 0, full * (size_t)B * D, st));
+  for (int b = 0; b < B; ++b) {
+    HP_REQUIRE(tbes[b] >= 0 && tbes[b] + tnum <= T, "hp_lct_time_window: window [%d, %d) of sample %d leaves [0, %d)", tbes[b],
+               tbes[b] + tnum, b, T);
+    float* yf = y_full + ((size_t)b * D * T + tbes[b]) * plane;
+    float* xw = x_window + (size_t)b * D * tnum * plane;
+    // D rows (channels) of tnum*plane floats: pitch T*plane in the full tensor, tnum*plane in the window
+    if (to_window) HP_CHECK_HIP(hipMemcpy2DAsync(xw, row, yf, full, row, (size_t)D, hipMemcpyDeviceToDevice, st));
+    else HP_CHECK_HIP(hipMemcpy2DAsync(yf, full, xw, row, row, (size_t)D, hipMemcpyDeviceToDevice, st));
+  }
+  return HP_OK;
+}

@@ -9,8 +9,8 @@ with `.forward(x, time_begin, time_end)` (:18-44), `LCT` (:46-257) and
 Differences from the reference, on purpose:
   * any batch size (the reference indexes 3-element time_begin/time_end lists, B <= 3);
   * constants live on the device of the input tensor (the reference hard-codes 'cuda');
-  * only tbe = 0, ten = T is accepted -- the only case NlosPose issues
-    (models/NlosPose.py:53); other windows raise.
+  * partial time windows (tbe, ten) -- NlosPose itself only issues tbe = 0, ten = T (models/NlosPose.py:53) --
+    are placed on the zero time axis by hp_lct_time_window before the transform.
 """
 from __future__ import annotations
 
@@ -78,6 +78,35 @@ class _LCTFunction(torch.autograd.Function):
         return ctx.plan.run(gy.contiguous(), backward=True), None
 
 
+class _TimeWindow(torch.autograd.Function):
+    """models/feature_propagation.py:193-200: equal-length samples at per-sample offsets of a zero time axis."""
+
+    @staticmethod
+    def forward(ctx, x, tbes, T):
+        import ctypes as C
+
+        b, d, t, h, w = x.shape
+        x = x.contiguous()
+        y = torch.empty(b, d, T, h, w, dtype=torch.float32, device=x.device)
+        arr = (C.c_int * b)(*[int(v) for v in tbes])
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_lct_time_window(y.data_ptr(), x.data_ptr(), b, d, t, T, h * w, arr, 0,
+                                                     _lib.current_stream_handle(x.device)), "hp_lct_time_window")
+        ctx.meta = (arr, t, T)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        arr, t, T = ctx.meta
+        b, d, _, h, w = gy.shape
+        gy = gy.contiguous()
+        gx = torch.empty(b, d, t, h, w, dtype=torch.float32, device=gy.device)
+        with torch.cuda.device(gy.device):
+            _lib.check(_lib.lib().hp_lct_time_window(gy.data_ptr(), gx.data_ptr(), b, d, t, T, h * w, arr, 1,
+                                                     _lib.current_stream_handle(gy.device)), "hp_lct_time_window")
+        return gx, None, None
+
+
 class LCT(nn.Module):
     """models/feature_propagation.py:46-257 (mode 'lct')."""
 
@@ -114,14 +143,17 @@ class LCT(nn.Module):
     def forward(self, feture_bxdxtxhxw, tbes=None, tens=None):
         x = feture_bxdxtxhxw
         b, d, t, h, w = x.shape
-        if tbes is not None:
-            for tbe, ten in zip(tbes, tens):
-                assert tbe >= 0 and ten <= self.time_size
-                if tbe != 0 or ten != self.time_size:
-                    raise NotImplementedError("only the full window tbe=0, ten=time_size is supported")
-        assert t == self.time_size and h == w == self.image_size
         if not x.is_cuda:
             raise _lib.HiddenPoseHipError("LCT.forward needs a tensor on a HIP device; there is no CPU path")
+        if tbes is not None:
+            assert len(tbes) >= b and len(tens) >= b
+            for tbe, ten in zip(tbes[:b], tens[:b]):
+                assert tbe >= 0 and ten <= self.time_size
+                assert ten - tbe == t, f"window [{tbe}, {ten}) does not hold {t} time bins"
+            if any(tbe != 0 or ten != self.time_size for tbe, ten in zip(tbes[:b], tens[:b])):
+                x = _TimeWindow.apply(x.float(), list(tbes[:b]), self.time_size)
+                t = self.time_size
+        assert t == self.time_size and h == w == self.image_size
         y = _LCTFunction.apply(x.reshape(b * d, t, h, w).float(), self.plan_for(x.device))
         return y.view(b, d, t, h, w)
 

@@ -79,6 +79,12 @@ int hp_lct_forward(const hp_lct_plan* plan, const float* x, float* y, int batch,
 /* gx = LCT^T(gy) (vector-Jacobian product of hp_lct_forward). */
 int hp_lct_backward(const hp_lct_plan* plan, const float* gy, float* gx, int batch,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* Time windows of LCT.forward (:193-200): sample b of x (B, D, tnum, H, W) is placed at time offset
+ * tbes[b] of the zero-initialised y (B, D, T, H, W) (to_window = 0), or cut back out of it (to_window = 1:
+ * x is written, the adjoint used by the backward pass).  tbes is a HOST array of B offsets with
+ * 0 <= tbes[b] and tbes[b] + tnum <= T.  Copy engine work only (memset + strided copies on `stream`). */
+int hp_lct_time_window(float* y_full, float* x_window, int B, int D, int tnum, int T, long plane, const int* tbes,
+                       int to_window, void* stream);
 /* Test hook: copy the device-resident inverse PSF back in natural (2T,2N,2N) order. */
 int hp_lct_plan_get_invpsf(const hp_lct_plan* plan, float* invpsf_re, float* invpsf_im);
 

@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax   (default: all)
+Sections: lctwin ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax   (default: all)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
 its filler keyed by state_dict name, so tests rebuild identical inputs and
@@ -337,6 +337,24 @@ def sec_schema():
           f"{sum(int(np.prod(v.shape)) for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k)} parameters")
 
 
+def sec_lctwin():
+    """LCT.forward with partial time windows (models/feature_propagation.py:186-200): samples of equal length
+    placed at different offsets inside the zero-padded time axis."""
+    import models.feature_propagation as fp
+
+    T, N = 32, 16
+    lct = fp.LCT(N, T, BIN_LEN[(T, N)], 2.0)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 1, 24, N, N, generator=g, requires_grad=True)
+    gy = torch.rand(2, 1, T, N, N, generator=g)
+    tbes, tens = [2, 5], [26, 29]
+    y = lct(x, tbes, tens)
+    (y * gy).sum().backward()
+    save("lct_window.npz", x=x.detach().numpy(), gy=gy.numpy(), tbes=np.array(tbes), tens=np.array(tens), y=y.detach().numpy(),
+         gx=x.grad.numpy())
+    print(f"  window: y {tuple(y.shape)} |y| {y.norm().item():.4g} |gx| {x.grad.norm().item():.4g}")
+
+
 def sec_ingest():
     """utils/loadrealdata.py:6-15 and NlosPoseDataset.__getitem__ (utils/nlos_pose_dataloader.py:71-144).
     cv2 is absent from this image: imread / cvtColor are the oracle's restatement of OpenCV's RGBE reader and
@@ -391,7 +409,7 @@ def sec_ingest():
              meas=meas, vol=v, joints=j, person_id=np.array(pid))
 
 
-SECTIONS = {"ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
+SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax}
 
 if __name__ == "__main__":

@@ -97,3 +97,20 @@ def test_full_size_vs_golden_samples(T, N, bin_len, golden):
     # linearity at full size: LCT(2x) == 2 LCT(x)
     y2 = lct((2 * x.detach()), [0], [T])
     assert rel_l2(y2.cpu().numpy(), 2 * y.detach().cpu().numpy()) < 1e-6
+
+
+def test_time_windows_vs_reference_golden(golden):
+    """LCT.forward(x, tbes, tens) with partial windows (models/feature_propagation.py:193-200), forward and the
+    gradient that flows back into the window."""
+    from hiddenpose_amd.feature_propagation import LCT
+
+    g = golden("lct_window.npz")
+    lct = LCT(16, 32, 0.16, 2.0)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = lct(x, [int(v) for v in g["tbes"]], [int(v) for v in g["tens"]])
+    assert y.shape == (2, 1, 32, 16, 16)
+    (y * torch.from_numpy(g["gy"]).cuda()).sum().backward()
+    assert rel_l2(y.detach().cpu().numpy(), g["y"]) < 2e-5
+    assert rel_l2(x.grad.cpu().numpy(), g["gx"]) < 2e-5
+    with pytest.raises(AssertionError):
+        lct(x, [0, 0], [32, 32])  # 24 time bins cannot fill a 32-bin window
