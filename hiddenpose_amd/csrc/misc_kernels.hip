@@ -160,24 +160,39 @@ __global__ __launch_bounds__(MT) void k_normalize_bwd_apply(const float* __restr
   }
 }
 
-// ---- soft-argmax: one workgroup per (b, joint) heat-map of D*H*W logits.
+// ---- soft-argmax over (b, joint) heat-maps of D*H*W logits, each split over SA_CHUNKS workgroups so that the
+// 4 x 24 maps fill the chip:  (1) max logit per map (ordered-integer atomicMax into stat[2 bj]),
+// (2) sum exp(l - max) and the three coordinate moments (fp32 atomics into stat[2 bj + 1], out[3 bj ..]),
+// (3) out /= sum and the max back as a float.
 // out[bj*3 + {0,1,2}] = E[w], E[h], E[d];  stat[bj*2 + {0,1}] = max logit, sum exp(l - max)
-__global__ __launch_bounds__(MT) void k_softargmax_fwd(const float* __restrict__ heat, float* __restrict__ out,
-                                                       float* __restrict__ stat, int D, int H, int W) {
-  __shared__ float sh[4 * MT / 64];
-  const long bj = blockIdx.x;
-  const long V = (long)D * H * W;
+constexpr int SA_CHUNKS = 32;
+
+__global__ __launch_bounds__(MT) void k_softargmax_max(const float* __restrict__ heat, float* __restrict__ stat, long V) {
+  __shared__ float sh[MT / 64];
+  const long bj = blockIdx.y;
+  const long per = (V + SA_CHUNKS - 1) / SA_CHUNKS, beg = blockIdx.x * per, end = min(V, beg + per);
   const float* p = heat + bj * V;
   float m = -FLT_MAX;
-  for (long i = threadIdx.x; i < V; i += MT) m = fmaxf(m, p[i]);
+  for (long i = beg + threadIdx.x; i < end; i += MT) m = fmaxf(m, p[i]);
   m = wmax(m);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
   __syncthreads();
-  m = sh[0];
-  for (int w = 1; w < MT / 64; ++w) m = fmaxf(m, sh[w]);
-  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < MT / 64; ++w) m = fmaxf(m, sh[w]);
+    atomicMax((unsigned int*)(stat + bj * 2), mono(m));
+  }
+}
+
+__global__ __launch_bounds__(MT) void k_softargmax_moments(const float* __restrict__ heat, float* __restrict__ out,
+                                                           float* __restrict__ stat, int D, int H, int W) {
+  __shared__ float sh[4 * MT / 64];
+  const long bj = blockIdx.y;
+  const long V = (long)D * H * W;
+  const long per = (V + SA_CHUNKS - 1) / SA_CHUNKS, beg = blockIdx.x * per, end = min(V, beg + per);
+  const float* p = heat + bj * V;
+  const float m = unmono(*(const unsigned int*)(stat + bj * 2));
   float s = 0.f, ex = 0.f, ey = 0.f, ez = 0.f;
-  for (long i = threadIdx.x; i < V; i += MT) {
+  for (long i = beg + threadIdx.x; i < end; i += MT) {
     const float e = __expf(p[i] - m);
     const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((long)W * H));
     s += e;
@@ -199,12 +214,21 @@ __global__ __launch_bounds__(MT) void k_softargmax_fwd(const float* __restrict__
     for (int w = 0; w < MT / 64; ++w) {
       a += sh[4 * w]; b += sh[4 * w + 1]; c += sh[4 * w + 2]; d += sh[4 * w + 3];
     }
-    out[bj * 3 + 0] = b / a;
-    out[bj * 3 + 1] = c / a;
-    out[bj * 3 + 2] = d / a;
-    stat[bj * 2] = m;
-    stat[bj * 2 + 1] = a;
+    atomicAdd(stat + bj * 2 + 1, a);
+    atomicAdd(out + bj * 3 + 0, b);
+    atomicAdd(out + bj * 3 + 1, c);
+    atomicAdd(out + bj * 3 + 2, d);
   }
+}
+
+__global__ void k_softargmax_finish(float* __restrict__ out, float* __restrict__ stat, int BJ) {
+  const int bj = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bj >= BJ) return;
+  const float a = stat[bj * 2 + 1];
+  out[bj * 3 + 0] /= a;
+  out[bj * 3 + 1] /= a;
+  out[bj * 3 + 2] /= a;
+  stat[bj * 2] = unmono(*(const unsigned int*)(stat + bj * 2));
 }
 
 // d logit_i = p_i * sum_a g_a (coord_a(i) - E_a)
@@ -336,8 +360,13 @@ extern "C" int hp_normalize_feature_backward(const float* dy, const float* x, fl
 extern "C" int hp_softargmax_forward(const float* heat, float* joints, float* stat, int BJ, int D, int H, int W, void* stream) {
   HP_REQUIRE(heat && joints && stat && BJ > 0, "hp_softargmax_forward: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  // zero bits: the smallest ordered key for the max, 0.0f for the sums
+  HP_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(float) * 2 * (size_t)BJ, st));
+  HP_CHECK_HIP(hipMemsetAsync(joints, 0, sizeof(float) * 3 * (size_t)BJ, st));
   HP_PROF("softargmax_fwd", st);
-  hipLaunchKernelGGL(k_softargmax_fwd, dim3(BJ), dim3(MT), 0, st, heat, joints, stat, D, H, W);
+  hipLaunchKernelGGL(k_softargmax_max, dim3(SA_CHUNKS, BJ), dim3(MT), 0, st, heat, stat, (long)D * H * W);
+  hipLaunchKernelGGL(k_softargmax_moments, dim3(SA_CHUNKS, BJ), dim3(MT), 0, st, heat, joints, stat, D, H, W);
+  hipLaunchKernelGGL(k_softargmax_finish, dim3((BJ + 63) / 64), dim3(64), 0, st, joints, stat, BJ);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
