@@ -186,6 +186,36 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply(const float4* __restrict__ 
   }
 }
 
+// Pass 2 for units without a residual: the masked gradient is not parked in memory by pass 1; the ReLU mask is
+// rebuilt here from z (the same affine map, bit for bit), so the unit's backward moves 5 tensors instead of 6.
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const float4* __restrict__ dy, const float4* __restrict__ z,
+                                                          float4* __restrict__ dz, long n4, int C4,
+                                                          const float4* __restrict__ ca, const float4* __restrict__ cb,
+                                                          const float4* __restrict__ cc, const float4* __restrict__ mean,
+                                                          const float4* __restrict__ rstd, const float4* __restrict__ gamma,
+                                                          const float4* __restrict__ beta, int relu) {
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    float4 gg = dy[i];
+    const float4 v = z[i], a = ca[c], b = cb[c], k = cc[c];
+    if (relu) {
+      const float4 m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+      const float4 sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
+      const float4 sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
+      gg.x = fmaf(v.x, sc.x, sh.x) > 0.f ? gg.x : 0.f;
+      gg.y = fmaf(v.y, sc.y, sh.y) > 0.f ? gg.y : 0.f;
+      gg.z = fmaf(v.z, sc.z, sh.z) > 0.f ? gg.z : 0.f;
+      gg.w = fmaf(v.w, sc.w, sh.w) > 0.f ? gg.w : 0.f;
+    }
+    float4 o;
+    o.x = a.x * gg.x + b.x * v.x + k.x;
+    o.y = a.y * gg.y + b.y * v.y + k.y;
+    o.z = a.z * gg.z + b.z * v.z + k.z;
+    o.w = a.w * gg.w + b.w * v.w + k.w;
+    dz[i] = o;
+  }
+}
+
 // MaxPool3d(kernel 3, stride 2, pad 1), channels-last
 __global__ __launch_bounds__(ET) void k_maxpool3_fwd(const float4* __restrict__ x, float4* __restrict__ y, int B, int D,
                                                      int H, int W, int C4) {
@@ -512,8 +542,10 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   float* cc = cb + C;
   HP_CHECK_HIP(hipMemsetAsync(red, 0, sizeof(double) * 2 * C, st));
   const int C4 = C / 4;
-  // g buffer: caller-provided g_out, or dz itself (pass 2 then runs in place)
-  float* gbuf = g_out ? g_out : dz;
+  // g buffer: caller-provided g_out (residual units: g is also the gradient of the shortcut), or none at all when
+  // pass 2 can rebuild the mask itself (no forward output given: mask from z, or no ReLU); dy must not alias dz then
+  const bool remask = !g_out && !y && dy != dz;
+  float* gbuf = remask ? nullptr : g_out ? g_out : dz;
   {
     HP_PROF("bn_bwd_reduce", st);
     const int rows_per_pass = C4 < ET ? ET / C4 : 1;
@@ -527,8 +559,13 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   {
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)gbuf, (const float4*)z,
-                       (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
+    if (remask)
+      hipLaunchKernelGGL(k_bn_bwd_apply_mask, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, (const float4*)z,
+                         (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean,
+                         (const float4*)rstd, (const float4*)gamma, (const float4*)beta_for_mask, relu);
+    else
+      hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)gbuf, (const float4*)z,
+                         (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
