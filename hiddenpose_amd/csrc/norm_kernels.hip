@@ -549,7 +549,7 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   {
     HP_PROF("bn_bwd_reduce", st);
     const int rows_per_pass = C4 < ET ? ET / C4 : 1;
-    const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 4);
+    const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(ET), 0, st, (const float4*)dy, (const float4*)y, (const float4*)z,
                        (float4*)gbuf, M, C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma,
                        (const float4*)beta_for_mask);
