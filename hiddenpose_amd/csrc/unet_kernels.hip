@@ -332,28 +332,36 @@ __global__ __launch_bounds__(UT) void k_upsample2_bwd(const float* __restrict__ 
     t /= D;
     const int c = (int)(t % C);
     const int b = (int)(t / C);
-    int lod, loh, low;
-    const int nd = adj_range(d, D, lod), nh = adj_range(h, H, loh), nw = adj_range(w, W, low);
-    const float* p = dy + ((long)b * Ctot + c_off + c) * Do * Ho * Wo;
-    float acc = 0.f;
-    for (int a = 0; a < nd; ++a) {
-      int i0, i1;
-      float f;
-      lerp_src(lod + a, D, i0, i1, f);
-      const float wd = (i0 == d ? 1.f - f : 0.f) + (i1 == d ? f : 0.f);
-      if (wd == 0.f) continue;
-      for (int bb = 0; bb < nh; ++bb) {
-        lerp_src(loh + bb, H, i0, i1, f);
-        const float wh = (i0 == h ? 1.f - f : 0.f) + (i1 == h ? f : 0.f);
-        if (wh == 0.f) continue;
-        for (int cc = 0; cc < nw; ++cc) {
-          lerp_src(low + cc, W, i0, i1, f);
-          const float ww = (i0 == w ? 1.f - f : 0.f) + (i1 == w ? f : 0.f);
-          if (ww == 0.f) continue;
-          acc += wd * wh * ww * p[((long)(lod + a) * Ho + loh + bb) * Wo + low + cc];
+    // per axis: the outputs that read this input voxel and their interpolation weights (at most 5; weights are
+    // separable, so the per-axis lists are built once instead of inside the triple loop)
+    int od[8], oh[8], ow[8], nd = 0, nh = 0, nw = 0;
+    float wd[8], wh[8], ww[8];
+    auto axis = [&](int pos, int n, int* idx, float* wt, int& cnt) {
+      int lo;
+      const int m = adj_range(pos, n, lo);
+      for (int a = 0; a < m; ++a) {
+        int i0, i1;
+        float f;
+        lerp_src(lo + a, n, i0, i1, f);
+        const float wgt = (i0 == pos ? 1.f - f : 0.f) + (i1 == pos ? f : 0.f);
+        if (wgt != 0.f && cnt < 8) {
+          idx[cnt] = lo + a;
+          wt[cnt] = wgt;
+          ++cnt;
         }
       }
-    }
+    };
+    axis(d, D, od, wd, nd);
+    axis(h, H, oh, wh, nh);
+    axis(w, W, ow, ww, nw);
+    const float* p = dy + ((long)b * Ctot + c_off + c) * Do * Ho * Wo;
+    float acc = 0.f;
+    for (int a = 0; a < nd; ++a)
+      for (int bb = 0; bb < nh; ++bb) {
+        const float wab = wd[a] * wh[bb];
+        const float* row = p + ((long)od[a] * Ho + oh[bb]) * Wo;
+        for (int cc = 0; cc < nw; ++cc) acc += wab * ww[cc] * row[ow[cc]];
+      }
     dx[i] = acc;
   }
 }
