@@ -869,6 +869,41 @@ __global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ o
   }
 }
 
+// The same mapping through a 64 x taps LDS tile so that BOTH sides move contiguous runs: the torch side in runs
+// of `taps` floats (t fastest), the packed side in runs of 64 inner channels.  grid (inner chunks of 64, outer).
+__global__ __launch_bounds__(256) void k_pack_weight_tiled(const float* __restrict__ w, float* __restrict__ out, int Cout,
+                                                           int Cin, int taps, int transposed, int swap, int to_torch) {
+  __shared__ float tile[64][65];
+  const int A = swap ? Cin : Cout, Bn = swap ? Cout : Cin;  // packed [t][A][Bn]
+  const int a = blockIdx.y, bn0 = blockIdx.x * 64;
+  const int nb = min(64, Bn - bn0), n = nb * taps;
+  auto torch_index = [&](int bn, int t) -> long {
+    const int co = swap ? bn : a, ci = swap ? a : bn;
+    return transposed ? ((long)ci * Cout + co) * taps + t : ((long)co * Cin + ci) * taps + t;
+  };
+  if (!to_torch) {
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int bl = e / taps, t = e - bl * taps;
+      tile[bl][t] = w[torch_index(bn0 + bl, t)];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < taps * 64; e += 256) {
+      const int t = e >> 6, bl = e & 63;
+      if (bl < nb) out[((long)t * A + a) * Bn + bn0 + bl] = tile[bl][t];
+    }
+  } else {
+    for (int e = threadIdx.x; e < taps * 64; e += 256) {
+      const int t = e >> 6, bl = e & 63;
+      if (bl < nb) tile[bl][t] = out[((long)t * A + a) * Bn + bn0 + bl];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const int bl = e / taps, t = e - bl * taps;
+      ((float*)w)[torch_index(bn0 + bl, t)] = tile[bl][t];
+    }
+  }
+}
+
 // stem: torch (64,1,7,7,7) <-> [64][kpad] (taps along K, zero padded)
 __global__ void k_pack_stem(const float* __restrict__ w, float* __restrict__ out, int Cout, int kpad, int to_torch) {
   const long total = (long)Cout * kpad;
@@ -1028,13 +1063,14 @@ extern "C" int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch
     if (w_fwd) hipLaunchKernelGGL(k_pack_stem, dim3(64), dim3(256), 0, st, w_torch, w_fwd, d->Cout, kpad, 0);
     if (w_dgrad) hipLaunchKernelGGL(k_pack_weight, dim3(64), dim3(256), 0, st, w_torch, w_dgrad, d->Cout, 1, 343, 0, 1, 0);
   } else {
-    const long total = (long)d->Cout * d->Cin * taps;
-    const unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+    HP_REQUIRE(taps <= 64, "conv: at most 64 taps (got %d)", taps);
     HP_PROF("conv_pack_weight", st);
-    if (w_fwd) hipLaunchKernelGGL(k_pack_weight, dim3(nb), dim3(256), 0, st, w_torch, w_fwd, d->Cout, d->Cin, taps,
-                                  d->transposed, 0, 0);
-    if (w_dgrad) hipLaunchKernelGGL(k_pack_weight, dim3(nb), dim3(256), 0, st, w_torch, w_dgrad, d->Cout, d->Cin, taps,
-                                    d->transposed, 1, 0);
+    if (w_fwd)
+      hipLaunchKernelGGL(k_pack_weight_tiled, dim3((d->Cin + 63) / 64, d->Cout), dim3(256), 0, st, w_torch, w_fwd, d->Cout,
+                         d->Cin, taps, d->transposed, 0, 0);
+    if (w_dgrad)
+      hipLaunchKernelGGL(k_pack_weight_tiled, dim3((d->Cout + 63) / 64, d->Cin), dim3(256), 0, st, w_torch, w_dgrad, d->Cout,
+                         d->Cin, taps, d->transposed, 1, 0);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
@@ -1051,10 +1087,8 @@ extern "C" int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_pac
   if (p.stem) {
     hipLaunchKernelGGL(k_pack_stem, dim3(64), dim3(256), 0, st, dw_torch, (float*)dw_packed, d->Cout, p.fwd.kpt * BK, 1);
   } else {
-    const long total = (long)d->Cout * d->Cin * taps;
-    const unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_pack_weight, dim3(nb), dim3(256), 0, st, dw_torch, (float*)dw_packed, d->Cout, d->Cin, taps,
-                       d->transposed, 0, 1);
+    hipLaunchKernelGGL(k_pack_weight_tiled, dim3((d->Cin + 63) / 64, d->Cout), dim3(256), 0, st, dw_torch, (float*)dw_packed,
+                       d->Cout, d->Cin, taps, d->transposed, 0, 1);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
