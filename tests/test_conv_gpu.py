@@ -31,6 +31,9 @@ CASES = [
     ("deconv", 64, 32, 4, 2, 1, True, (2, 3, 4, 2)),
     ("stem", 1, 64, 7, 1, 3, False, (1, 10, 12, 9)),
     ("head", 256, 24, 1, 1, 0, False, (1, 4, 4, 4)),
+    # long and wide: >= 131072 voxels, 256 output channels (forward; data gradient)
+    ("big_fwd256", 32, 256, 1, 1, 0, False, (1, 32, 64, 64)),
+    ("big_dgrad256", 256, 32, 1, 1, 0, False, (1, 33, 64, 64)),
 ]
 
 
