@@ -138,6 +138,7 @@ def bench_sformer(args):
     kw = dict(dim=256, num_frames=16, num_joints=24, image_size=128, patch_size=4, channels=1, depth=8, heads=8,
               dim_head=32, out_dim=512)
     model = NlosPoseSformer(**kw).cuda().eval()
+    model.linear_precision = args.conv_precision  # fp32 (default) or a bf16 matrix-core mode for the Linear GEMMs
     video = torch.rand(B, 16, 1, 128, 128, device="cuda")
     for _ in range(args.warmup):
         model(video)
@@ -158,7 +159,8 @@ def bench_sformer(args):
     print(json.dumps({
         "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.conv_precision == "fp32" else f"{args.conv_precision} linears, f32 attention", "data": "synthetic",
         "config": {"workload": f"NlosPoseSformer forward, batch {B}, 16 frames x 128x128, patch 4, dim 256, depth 8, "
                                "8 heads x 32, random-init weights"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},

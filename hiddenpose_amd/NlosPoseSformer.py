@@ -62,19 +62,26 @@ class _FeedForward(nn.Module):
         self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), nn.Identity(), nn.Identity(), nn.Linear(dim * mult, dim))
 
 
-def _linear(x2d, weight, bias):
+_LINEAR_PRECISION = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}  # HP_PRECISION_*
+
+
+def _linear(x2d, weight, bias, precision=0):
     """y = x @ W^T + b through hp_conv3d_forward (k = 1).  x2d (M, K) contiguous."""
     L = _lib.lib()
     M, K = x2d.shape
     N = weight.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x2d.device)
-    desc = _lib.ConvDesc(1, 1, 1, M, K, N, 1, 1, 0, 0)
+    desc = _lib.ConvDesc(1, 1, 1, M, K, N, 1, 1, 0, 0, precision)
     _lib.check(L.hp_conv3d_forward(C.byref(desc), x2d.data_ptr(), weight.data_ptr(), _lib.ptr(bias), y.data_ptr(), None,
                                    _lib.current_stream_handle(x2d.device)), "hp_conv3d_forward(linear)")
     return y
 
 
 class NlosPoseSformer(nn.Module):
+    # arithmetic of the transformer-layer Linear GEMMs: "fp32" (exact, default) or the bf16 matrix-core modes of
+    # hp_conv_desc.precision; attention, LayerNorm, GEGLU, patch embedding and the output head stay fp32
+    linear_precision = "fp32"
+
     def __init__(self, *, dim, num_frames, num_joints=24, image_size=224, patch_size=16, channels=2, depth=12, heads=8,
                  dim_head=64, attn_dropout=0.0, ff_dropout=0.0, rotary_emb=True, out_dim=64 * 2 * 3, batch_size=2):
         super().__init__()
@@ -108,6 +115,7 @@ class NlosPoseSformer(nn.Module):
         dim = self.joints_token.shape[-1]
         dev = video.device
         st = _lib.current_stream_handle(dev)
+        prec = _LINEAR_PRECISION[self.linear_precision]
         with torch.cuda.device(dev):
             tokens = torch.empty(b * f * n, ps * ps * c, dtype=torch.float32, device=dev)
             _lib.check(L.hp_sformer_patchify(video.data_ptr(), tokens.data_ptr(), b, f, c, H, W, ps, st), "hp_sformer_patchify")
@@ -130,21 +138,21 @@ class NlosPoseSformer(nn.Module):
                 a = spatial.fn
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, spatial.norm.weight.data_ptr(),
                                                   spatial.norm.bias.data_ptr(), spatial.norm.eps, 0, 0, st), "hp_layernorm_forward")
-                qkv = _linear(h.view(rows, dim), a.to_qkv.weight, None)
+                qkv = _linear(h.view(rows, dim), a.to_qkv.weight, None, prec)
                 _lib.check(L.hp_sformer_qkv_prepare(qkv.data_ptr(), q.data_ptr(), k.data_ptr(), k0.data_ptr(), v.data_ptr(), b, ntok, heads, dh,
                                                     nj, n, a.scale, sin_t.data_ptr(), cos_t.data_ptr(), rot_dim, st),
                            "hp_sformer_qkv_prepare")
                 _lib.check(L.hp_sformer_attention(q.data_ptr(), k.data_ptr(), k0.data_ptr(), v.data_ptr(), att.data_ptr(), b, heads, dh, ntok, nj,
                                                   n, f, aws.data_ptr(), st), "hp_sformer_attention")
-                proj = _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias)
+                proj = _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias, prec)
                 _lib.check(L.hp_leaky_add_forward(x.data_ptr(), proj.data_ptr(), x.data_ptr(), x.numel(), 1.0, st), "residual add")
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, ff.norm.weight.data_ptr(),
                                                   ff.norm.bias.data_ptr(), ff.norm.eps, 0, 0, st), "hp_layernorm_forward")
-                u = _linear(h.view(rows, dim), ff.fn.net[0].weight, ff.fn.net[0].bias)
+                u = _linear(h.view(rows, dim), ff.fn.net[0].weight, ff.fn.net[0].bias, prec)
                 hid = ff.fn.net[3].weight.shape[1]
                 g = torch.empty(rows, hid, dtype=torch.float32, device=dev)
                 _lib.check(L.hp_geglu_forward(u.data_ptr(), g.data_ptr(), rows, hid, st), "hp_geglu_forward")
-                d = _linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias)
+                d = _linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, prec)
                 _lib.check(L.hp_leaky_add_forward(x.data_ptr(), d.data_ptr(), x.data_ptr(), x.numel(), 1.0, st), "residual add")
             jt = torch.empty(b * nj, dim, dtype=torch.float32, device=dev)
             _lib.check(L.hp_layernorm_forward(x.data_ptr(), jt.data_ptr(), b * nj, dim, self.to_out[0].weight.data_ptr(),

@@ -66,3 +66,15 @@ def test_hip_forward_config5_shape_vs_oracle():
     ref = O.nlospose_sformer(video, sd, patch_size=4, heads=8)
     y = m.cuda()(video.cuda())
     assert rel_l2(y, ref) < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_forward_bf16_linears_vs_reference_golden(golden):
+    """Opt-in bf16 matrix-core Linear layers (BASELINE config 5 asks for reduced-precision MFMA): 2^-9 operand
+    rounding through 2 layers: measured 1.1e-2 of the reference output (bar 3e-2); bf16x3 within 1e-4."""
+    kw, m, video = build("small")
+    m = m.cuda()
+    for prec, tol in (("bf16", 3e-2), ("bf16x3", 1e-4)):
+        m.linear_precision = prec
+        y = m(video.cuda())
+        assert rel_l2(y, golden("sformer_io.npz")["small_y"]) < tol, prec
