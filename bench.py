@@ -139,6 +139,7 @@ def bench_sformer(args):
               dim_head=32, out_dim=512)
     model = NlosPoseSformer(**kw).cuda().eval()
     model.linear_precision = args.conv_precision  # fp32 (default) or a bf16 matrix-core mode for the Linear GEMMs
+    model.attention_precision = "bf16" if args.conv_precision == "bf16" else "fp32"
     video = torch.rand(B, 16, 1, 128, 128, device="cuda")
     for _ in range(args.warmup):
         model(video)
@@ -160,7 +161,9 @@ def bench_sformer(args):
         "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.conv_precision == "fp32" else f"{args.conv_precision} linears, f32 attention", "data": "synthetic",
+        "dtype": "f32" if args.conv_precision == "fp32" else
+                 "bf16 linears + bf16 patch attention (f32 soft-max)" if args.conv_precision == "bf16" else
+                 f"{args.conv_precision} linears, f32 attention", "data": "synthetic",
         "config": {"workload": f"NlosPoseSformer forward, batch {B}, 16 frames x 128x128, patch 4, dim 256, depth 8, "
                                "8 heads x 32, random-init weights"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},

@@ -81,6 +81,8 @@ class NlosPoseSformer(nn.Module):
     # arithmetic of the transformer-layer Linear GEMMs: "fp32" (exact, default) or the bf16 matrix-core modes of
     # hp_conv_desc.precision; attention, LayerNorm, GEGLU, patch embedding and the output head stay fp32
     linear_precision = "fp32"
+    # patch-token attention: "fp32" (exact-fp32 MFMA, default) or "bf16" (bf16 matrix cores, fp32 soft-max; dim_head 32)
+    attention_precision = "fp32"
 
     def __init__(self, *, dim, num_frames, num_joints=24, image_size=224, patch_size=16, channels=2, depth=12, heads=8,
                  dim_head=64, attn_dropout=0.0, ff_dropout=0.0, rotary_emb=True, out_dim=64 * 2 * 3, batch_size=2):
@@ -116,6 +118,9 @@ class NlosPoseSformer(nn.Module):
         dev = video.device
         st = _lib.current_stream_handle(dev)
         prec = _LINEAR_PRECISION[self.linear_precision]
+        aprec = {"fp32": 0, "bf16": 1}[self.attention_precision]
+        if aprec and dh != 32:
+            raise _lib.HiddenPoseHipError("bf16 attention is built for dim_head 32 only")
         with torch.cuda.device(dev):
             tokens = torch.empty(b * f * n, ps * ps * c, dtype=torch.float32, device=dev)
             _lib.check(L.hp_sformer_patchify(video.data_ptr(), tokens.data_ptr(), b, f, c, H, W, ps, st), "hp_sformer_patchify")
@@ -143,7 +148,7 @@ class NlosPoseSformer(nn.Module):
                                                     nj, n, a.scale, sin_t.data_ptr(), cos_t.data_ptr(), rot_dim, st),
                            "hp_sformer_qkv_prepare")
                 _lib.check(L.hp_sformer_attention(q.data_ptr(), k.data_ptr(), k0.data_ptr(), v.data_ptr(), att.data_ptr(), b, heads, dh, ntok, nj,
-                                                  n, f, aws.data_ptr(), st), "hp_sformer_attention")
+                                                  n, f, aprec, aws.data_ptr(), st), "hp_sformer_attention")
                 proj = _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias, prec)
                 _lib.check(L.hp_leaky_add_forward(x.data_ptr(), proj.data_ptr(), x.data_ptr(), x.numel(), 1.0, st), "residual add")
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, ff.norm.weight.data_ptr(),

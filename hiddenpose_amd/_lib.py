@@ -86,7 +86,7 @@ SIGNATURES = {
     "hp_ingest_rgbe_to_meas": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "hp_box_downsample_round": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),
     "hp_pair_average_axis0": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),
-    "hp_sformer_attention": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "hp_sformer_attention": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
 

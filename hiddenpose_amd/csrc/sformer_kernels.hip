@@ -283,6 +283,119 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
   }
 }
 
+
+// Patch-token attention on the bf16 matrix cores (dim_head 32; BASELINE config 5 "MFMA fp16 attention").
+// Same dataflow as k_attention mode 0 -- S^T = K Q^T puts one query per lane, the soft-max stays in fp32
+// registers, O^T += V^T P consumes P exactly as it lies in the accumulator -- but each 32-key tile is
+// 2 + 2 v_mfma_f32_32x32x16_bf16 instead of 16 + 16 fp32 MFMAs.  The MFMA k-slots of step t are mapped to the
+// accumulator rows the lane already holds (slot (half, j) <-> register 8t + j <-> key (j&3) + 8(2t + (j>>2)) + 4 half),
+// and the V tile is staged transposed with its keys in that slot order, so both P and V^T are one 16-byte read.
+using bf16x8s = __attribute__((ext_vector_type(8))) __bf16;
+__global__ __launch_bounds__(ST) void k_attention_patch_bf16(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ V, float* __restrict__ out, int heads,
+                                                             int Ntok, int nj, int n, int frames) {
+  constexpr int DH = 32, LDB = DH + 8;  // 80-byte rows: the 16-byte fragment reads of 32 rows spread over all banks
+  __shared__ __attribute__((aligned(16))) __bf16 Kh[32 * LDB];   // [key][d]
+  __shared__ __attribute__((aligned(16))) __bf16 Vt[32 * LDB];   // [d][key slot]
+  __shared__ float os[4][32 * (DH + 1)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  const int bh = blockIdx.y / frames, f = blockIdx.y % frames;
+  const int b = bh / heads, head = bh % heads;
+  const float* Qb = Q + (long)bh * Ntok * DH;
+  const float* Kb = K + (long)bh * Ntok * DH;
+  const float* Vb = V + (long)bh * Ntok * DH;
+  const int nkeys = nj + n;
+  const int qi = blockIdx.x * 128 + wave * 32 + col;
+  const bool qvalid = qi < n;
+  const int qtok = nj + f * n + qi;
+  // B operand of S^T: this lane's query, d = 16 s + 8 half .. + 7
+  bf16x8s qf[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[s2][j] = (__bf16)(qvalid ? Qb[(long)qtok * DH + 16 * s2 + 8 * half + j] : 0.f);
+
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  float m = -FLT_MAX, l = 0.f;
+  const int ntiles = (nkeys + 31) / 32;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    __syncthreads();
+    {  // 32 keys x 8 channel quads = one float4 of K and of V per thread
+      const int kr = tid >> 3, d = (tid & 7) * 4;
+      const int kj = tile * 32 + kr;
+      float4 kv = make_float4(0, 0, 0, 0), vv = kv;
+      if (kj < nkeys) {
+        const int tok = kj < nj ? kj : nj + f * n + (kj - nj);
+        kv = *(const float4*)(Kb + (long)tok * DH + d);
+        vv = *(const float4*)(Vb + (long)tok * DH + d);
+      }
+      __bf16* kd = Kh + kr * LDB + d;
+      kd[0] = (__bf16)kv.x;
+      kd[1] = (__bf16)kv.y;
+      kd[2] = (__bf16)kv.z;
+      kd[3] = (__bf16)kv.w;
+      const int slot = (kr >> 4) * 16 + ((kr >> 2) & 1) * 8 + (kr & 3) + 4 * ((kr >> 3) & 1);
+      Vt[(d + 0) * LDB + slot] = (__bf16)vv.x;
+      Vt[(d + 1) * LDB + slot] = (__bf16)vv.y;
+      Vt[(d + 2) * LDB + slot] = (__bf16)vv.z;
+      Vt[(d + 3) * LDB + slot] = (__bf16)vv.w;
+    }
+    __syncthreads();
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8s*)(Kh + col * LDB + 16 * s2 + 8 * half), qf[s2], sacc, 0, 0, 0);
+    float tm = -FLT_MAX;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (key >= nkeys) sacc[r] = -FLT_MAX;
+      tm = fmaxf(tm, sacc[r]);
+    }
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    const float mn = fmaxf(m, tm);
+    const float alpha = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = sacc[r] > -FLT_MAX ? __expf(sacc[r] - mn) : 0.f;
+      sacc[r] = pr;
+      ps += pr;
+    }
+    ps += __shfl_xor(ps, 32);
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8s pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[8 * t + j];
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8s*)(Vt + col * LDB + 16 * t + 8 * half), pf, oacc, 0, 0, 0);
+    }
+  }
+  // normalise, transpose through LDS and store 128-byte rows
+  const int inner = heads * DH;
+  float* o = os[wave];
+  const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+    o[col * (DH + 1) + d] = oacc[r] * inv;
+  }
+  __syncthreads();
+  for (int i = lane; i < 32 * DH; i += 64) {
+    const int qr = i / DH, d = i - qr * DH;
+    const int q2 = blockIdx.x * 128 + wave * 32 + qr;
+    if (q2 < n) out[((long)b * Ntok + nj + f * n + q2) * inner + head * DH + d] = o[qr * (DH + 1) + d];
+  }
+}
+
 // merge the key splits of the joint-token attention: one thread per (bh, query, d)
 __global__ void k_attention_joint_merge(const float* __restrict__ part, float* __restrict__ out, int BH, int heads, int dh,
                                         int Ntok, int nq, int nsplit) {
@@ -361,9 +474,12 @@ extern "C" size_t hp_sformer_attention_workspace_bytes(int B, int heads, int dh)
 
 extern "C" int hp_sformer_attention(const float* Q, const float* K, const float* K0, const float* V, float* out, int B,
                                     int heads, int dh,
-                                    int Ntok, int num_joints, int patches_per_frame, int frames, void* workspace, void* stream) {
+                                    int Ntok, int num_joints, int patches_per_frame, int frames, int precision,
+                                    void* workspace, void* stream) {
   HP_REQUIRE(Q && K && K0 && V && out && workspace, "hp_sformer_attention: null argument");
   HP_REQUIRE(num_joints <= 32 && Ntok == num_joints + frames * patches_per_frame, "hp_sformer_attention: bad token layout");
+  HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_sformer_attention: precision %d not built",
+             precision);
   if (dh != 16 && dh != 32) {
     set_error("hp_sformer_attention: dim_head %d not built (16, 32)", dh);
     return HP_ERR_UNSUPPORTED;
@@ -375,7 +491,10 @@ extern "C" int hp_sformer_attention(const float* Q, const float* K, const float*
   const dim3 gp((patches_per_frame + 127) / 128, B * heads * frames), gj(nsplit, B * heads);
   {
     HP_PROF("sformer_attention_patch", st);
-    if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
+    if (dh == 32 && precision == HP_PRECISION_BF16)
+      hipLaunchKernelGGL(k_attention_patch_bf16, gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame,
+                         frames);
+    else if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
     else hipLaunchKernelGGL((k_attention<16>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
   }
   {

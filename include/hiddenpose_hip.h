@@ -260,9 +260,11 @@ int hp_sformer_qkv_prepare(const float* qkv, float* Q, float* K, float* K0, floa
 /* spatial attention with joint tokens (:284-319): joint queries attend to all tokens, patch queries to
  * [joint tokens | patches of their frame]; out (B, Ntok, heads*dh) with heads merged. */
 size_t hp_sformer_attention_workspace_bytes(int B, int heads, int dh);
+/* precision: HP_PRECISION_FP32 (exact-fp32 MFMA) or HP_PRECISION_BF16 (patch-token attention with bf16 operands on
+ * the bf16 matrix cores, fp32 soft-max and accumulation, dim_head 32; the 24 joint queries stay fp32). */
 int hp_sformer_attention(const float* Q, const float* K, const float* K0, const float* V, float* out, int B, int heads,
-                         int dh, int Ntok,
-                         int num_joints, int patches_per_frame, int frames, void* workspace, void* stream);
+                         int dh, int Ntok, int num_joints, int patches_per_frame, int frames, int precision,
+                         void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------
  * Measurement ingest (utils/nlos_pose_dataloader.py:71-144, utils/loadrealdata.py:6-15): the per-sample

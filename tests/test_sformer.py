@@ -78,3 +78,23 @@ def test_hip_forward_bf16_linears_vs_reference_golden(golden):
         m.linear_precision = prec
         y = m(video.cuda())
         assert rel_l2(y, golden("sformer_io.npz")["small_y"]) < tol, prec
+
+
+@pytest.mark.gpu
+def test_hip_bf16_attention_config5_shape_vs_oracle():
+    """bf16 matrix-core patch attention (dim_head 32) at the config 5 geometry, batch 1, against the oracle: the
+    Linear layers stay fp32 so the difference is the attention alone."""
+    kw = dict(dim=256, num_frames=16, num_joints=24, image_size=128, patch_size=4, channels=1, depth=8, heads=8,
+              dim_head=32, out_dim=512)
+    m = NlosPoseSformer(**kw)
+    hpt.fill_module(m, "sformer.")
+    video = torch.rand(1, 16, 1, 128, 128, generator=torch.Generator().manual_seed(5))
+    sd = {"sformer." + k: v for k, v in m.state_dict().items()}
+    ref = O.nlospose_sformer(video, sd, patch_size=4, heads=8)
+    m = m.cuda()
+    y32 = m(video.cuda())
+    m.attention_precision = "bf16"
+    y16 = m(video.cuda())
+    e32, e16 = rel_l2(y32, ref), rel_l2(y16, ref)
+    print(f"config-5 geometry: fp32 attention {e32:.2e}, bf16 attention {e16:.2e}")
+    assert e32 < 1e-3 and e16 < 2e-2
