@@ -787,23 +787,36 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   const int col = lane & 31, gi_l = col >> 3, kw_l = col & 7, half = lane >> 5;
   // staging write address of accumulator register r: lane part + compile-time register part
   const int sw_lane = ((gi_l * SP_Y) * SR_X + 4 * half + kw_l) * SG_KW + kw_l;
-  for (int chunk = 0; chunk < 14; ++chunk) {
+  // weight chunk c+1 is fetched into registers while chunk c is multiplied and folded
+  float4 wv[2];
+  auto fetch_w = [&](int chunk) {
     const int kd = chunk >> 1, kh0 = (chunk & 1) * 4, npair = (chunk & 1) ? 3 : 4;
-    __syncthreads();  // previous chunk: fragment reads, gather reads and patch updates are finished
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int i = tid + h * CT;  // 512 float4 = 32 columns x 16 quads
       const int tr = i >> 4, q = i & 15;
       const int gi = tr >> 3, kw = tr & 7;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (gi < npair && kw < 7) v = *(const float4*)(Wt + (long)(((kd * 7) + kh0 + gi) * 7 + kw) * 64 + q * 4);
+      wv[h] = (gi < npair && kw < 7) ? *(const float4*)(Wt + (long)(((kd * 7) + kh0 + gi) * 7 + kw) * 64 + q * 4)
+                                     : make_float4(0, 0, 0, 0);
+    }
+  };
+  fetch_w(0);
+  for (int chunk = 0; chunk < 14; ++chunk) {
+    const int kd = chunk >> 1, kh0 = (chunk & 1) * 4, npair = (chunk & 1) ? 3 : 4;
+    __syncthreads();  // previous chunk: fragment reads, gather reads and patch updates are finished
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = tid + h * CT;
+      const int tr = i >> 4, q = i & 15;
       float* d = Bs + tr * SLD + q * 4;
-      d[0] = v.x;
-      d[1] = v.y;
-      d[2] = v.z;
-      d[3] = v.w;
+      d[0] = wv[h].x;
+      d[1] = wv[h].y;
+      d[2] = wv[h].z;
+      d[3] = wv[h].w;
     }
     __syncthreads();
+    if (chunk + 1 < 14) fetch_w(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
