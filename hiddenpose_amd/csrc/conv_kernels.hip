@@ -860,6 +860,154 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   }
 }
 
+
+// ---------------------------------------------------------------- stem forward on the 4x4x1 matrix-core instruction
+// The stem (1 -> 64 channels, 7^3 taps) as a GEMM has K = 343 taps of a single-channel volume: the generic kernel
+// gathers its A tile element by element.  With v_mfma_f32_4x4x1_16b_f32 (16 blocks of a 4x4 outer product; row i =
+// output channel 4 cg + i, column j / block b = voxel 4b + j of a 64-voxel x-run) every tap needs ONE shifted
+// ds_read_b32 of the input plane, shared by the 16 channel groups, and no gather at all:
+//     D_b[i][j] += w[4 cg + i][tap] * x[v_{4b+j} + tap]
+// A workgroup owns an 8 (y) x 64 (x) output column and slides along z: 8-slot LDS ring of padded input planes
+// (14 rows x 72 columns), the whole weight tensor resident in LDS as [tap][i][cg] (88 KB; 4 broadcast 16-byte reads
+// per tap), 128 accumulators per wave (2 rows x 16 groups x 4).  Epilogue per row: transpose through LDS, per-channel
+// sum / sum of squares for the BatchNorm statistics, 128-byte channels-last stores.  Exact fp32 (fmaf chain per
+// output, taps in ascending order as in the generic kernel).
+constexpr int SF_TY = 8, SF_TX = 64, SF_RY = SF_TY + 6, SF_RX = 72, SF_PLANE = SF_RY * SF_RX;
+using f32x4c = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void k_stem_fwd_mfma(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                       float* __restrict__ Y, double* __restrict__ stats, int D, int H, int W,
+                                                       int kpad, int tiles_x, int tiles_y, int zchunk) {
+  extern __shared__ __attribute__((aligned(16))) float sf_smem[];
+  float* const wl = sf_smem;                       // [343][4][16]
+  float* const ring = wl + 343 * 64;               // [8][SF_RY][SF_RX]
+  float* const otile = ring + 8 * SF_PLANE;        // [4 waves][64 voxels][33]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 3;
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y;
+  const int x0 = bx * SF_TX, y0 = by * SF_TY;
+  const int zb = bz * zchunk, ze = min(D, zb + zchunk);
+  const float* xb = X + (long)b * D * H * W;
+
+  for (int e = tid; e < 343 * 64; e += 256) {
+    const int cg = e & 15, i = (e >> 4) & 3, tap = e >> 6;
+    wl[e] = Wp[(long)(cg * 4 + i) * kpad + tap];
+  }
+  // staging map of one padded plane: element e = tid + 256 k of [14][72]
+  constexpr int SK = (SF_PLANE + 255) / 256;
+  int soff[SK];
+  unsigned smask = 0;
+#pragma unroll
+  for (int k = 0; k < SK; ++k) {
+    const int e = tid + 256 * k;
+    const int ly = e / SF_RX, lx = e - ly * SF_RX;
+    const int yy = y0 + ly - 3, xx = x0 + lx - 3;
+    const bool ok = e < SF_PLANE && lx < SF_TX + 6 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    soff[k] = ok ? yy * W + xx : 0;
+    smask |= ok ? (1u << k) : 0u;
+  }
+  auto stage = [&](int zin) {
+    float* dst = ring + (zin & 7) * SF_PLANE + tid;
+    const bool zok = (unsigned)zin < (unsigned)D;
+    const float* src = xb + (long)(zok ? zin : 0) * H * W;
+    float v[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+#pragma unroll
+    for (int k = 0; k < SK; ++k)
+      if (tid + 256 * k < SF_PLANE) dst[256 * k] = v[k];
+  };
+  if (zb < ze)
+    for (int zin = zb - 3; zin <= zb + 3; ++zin) stage(zin);
+  __syncthreads();
+
+  float* const ot = otile + wave * (64 * 33);
+  float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};  // this lane's channels 32 hh + (lane & 31), lanes < 32 only
+  for (int z = zb; z < ze; ++z) {
+    if (z + 1 < ze) stage(z + 4);  // replaces plane z - 4, last read one barrier ago
+    f32x4c acc[2][16];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int cg = 0; cg < 16; ++cg) acc[r][cg] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int a = 0; a < 7; ++a) {
+      const float* pl = ring + ((z + a - 3) & 7) * SF_PLANE + (2 * wave) * SF_RX + lane;
+#pragma unroll 1
+      for (int bb = 0; bb < 7; ++bb) {
+        const float* wt = wl + ((a * 7 + bb) * 7) * 64 + sub * 16;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          float wr[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4c t4 = *(const f32x4c*)(wt + c * 64 + 4 * q);
+            wr[4 * q] = t4[0];
+            wr[4 * q + 1] = t4[1];
+            wr[4 * q + 2] = t4[2];
+            wr[4 * q + 3] = t4[3];
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const float xv = pl[(r + bb) * SF_RX + c];
+#pragma unroll
+            for (int cg = 0; cg < 16; ++cg) acc[r][cg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[cg], xv, acc[r][cg], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lane l holds out[4 cg + i][row][x0 + l] in acc[row][cg][i]
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int oy = y0 + 2 * wave + r;
+      const bool row_ok = oy < H;
+      const long orow = (((long)b * D + z) * H + oy) * W + x0;  // first voxel of the run
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ot[lane * 33 + cg * 4 + i] = acc[r][8 * hh + cg][i];
+        // (LDS accesses of one wave are ordered; no barrier needed for a wave-private tile)
+        if (row_ok) {
+          if (stats && lane < 32) {
+            float s = 0.f, q = 0.f;
+            const int nv = min(64, W - x0);
+            for (int v = 0; v < nv; ++v) {
+              const float val = ot[v * 33 + lane];
+              s += val;
+              q += val * val;
+            }
+            ssum[hh] += s;
+            ssq[hh] += q;
+          }
+          const int q4 = lane & 7;
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int v = it * 8 + (lane >> 3);
+            if (x0 + v < W) {
+              const float* sp = ot + v * 33 + 4 * q4;
+              *(float4*)(Y + (orow + v) * 64 + 32 * hh + 4 * q4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (stats && lane < 32) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      atomicAdd(stats + 32 * hh + lane, (double)ssum[hh]);
+      atomicAdd(stats + 64 + 32 * hh + lane, (double)ssq[hh]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- weight (un)packing
 // torch Conv3d weight (Cout,Cin,k,k,k)  <->  packed [tap][Cout][Cin]   (transposed=0)
 // torch ConvTranspose3d weight (Cin,Cout,k,k,k) <-> packed [tap][Cout][Cin]   (transposed=1)
@@ -1115,7 +1263,23 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
-  {
+  if (p.stem && p.planes == 0 && d->Cout == 64 && !bias) {
+    // dedicated 4x4x1-MFMA stem kernel: ~1024 workgroups, one resident per CU (138 KB of LDS)
+    const int tiles_x = (d->Wi + SF_TX - 1) / SF_TX, tiles_y = (d->Hi + SF_TY - 1) / SF_TY;
+    const long cols = (long)tiles_x * tiles_y * d->B;
+    int zsplit = (int)std::max<long>(1, std::min<long>((d->Di + 15) / 16, (1024 + cols - 1) / cols));
+    const int zchunk = (d->Di + zsplit - 1) / zsplit;
+    zsplit = (d->Di + zchunk - 1) / zchunk;
+    const size_t lds = sizeof(float) * (343 * 64 + 8 * SF_PLANE + 4 * 64 * 33);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HP_CHECK_HIP(hipFuncSetAttribute((const void*)k_stem_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    HP_PROF("conv_igemm_stem", st);
+    hipLaunchKernelGGL(k_stem_fwd_mfma, dim3((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)d->B), dim3(256), lds, st, x, w_fwd,
+                       y, stats, d->Di, d->Hi, d->Wi, p.fwd.kpt * BK, tiles_x, tiles_y, zchunk);
+  } else {
     HP_PROF(p.stem ? "conv_igemm_stem" : d->transposed ? "conv_igemm_deconv" : d->k == 1 ? "conv_igemm_k1" : "conv_igemm_k3", st);
     launch_igemm(p.fwd, p.fwd_classes, p.stem, p.planes, x, w_fwd, bias, y, stats, nullptr, st);
   }
