@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd_mfma(const float* __restrict__
 #pragma unroll 1
     for (int a = 0; a < 7; ++a) {
       const float* pl = ring + ((z + a - 3) & 7) * SF_PLANE + (2 * wave) * SF_RX + lane;
-#pragma unroll 1
+#pragma unroll
       for (int bb = 0; bb < 7; ++bb) {
         const float* wt = wl + ((a * 7 + bb) * 7) * 64 + sub * 16;
 #pragma unroll
