@@ -861,6 +861,122 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
 }
 
 
+
+// ---------------------------------------------------------------- stem weight gradient, whole dW per workgroup
+// dW[co][tap] = sum_v dZ[v][co] * x[v + tap]  (64 x 343).  As a GEMM its output is only 64 x 352, so ONE
+// workgroup can hold all of it in accumulators (2 x 11 MFMA tiles over 4 waves): dZ -- the 8.6 GB operand -- is
+// then read exactly once instead of once per 64-wide tap tile, and the tap operand needs no gathered tile at
+// all: per 4x4x8-voxel tile the input patch (10 x 10 x 14) sits in LDS and lane (tap, half) reads
+// patch[voxel(k) + offset(tap)] directly.  Patch pitches 39 (row) and 401 (plane) are = 7 and 49 mod 32, so the
+// 32 consecutive taps of a fragment read fall on 32 consecutive banks.  A workgroup walks a contiguous range of
+// tiles, keeps its partial dW in registers and adds it to memory once at the end (fp32 atomics).
+constexpr int SWG_PR = 39, SWG_PP = 401, SWG_PATCH = 10 * SWG_PP, SWG_LDY = 65;
+
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad_full(const float* __restrict__ X, const float* __restrict__ dZ,
+                                                            float* __restrict__ dW, int D, int H, int W, int pz, int py,
+                                                            int px, long tiles_total, int tiles_per_wg, int kpad) {
+  __shared__ float Ys[SP_M * SWG_LDY];
+  __shared__ float patch[SWG_PATCH + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  // this wave's tap tiles: wave, wave + 4, wave + 8 (11 tiles of 32 taps cover 352 >= 343)
+  int toff[3];
+  bool tval[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tap = 32 * (wave + 4 * j) + col;
+    tval[j] = wave + 4 * j < 11 && tap < 343;
+    const int a = tap / 49, bb = (tap / 7) % 7, c = tap % 7;
+    toff[j] = tval[j] ? a * SWG_PP + bb * SWG_PR + c : 0;
+  }
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (tid < 8) patch[SWG_PATCH + tid] = 0.f;  // the cell invalid taps read
+
+  const long t0 = (long)blockIdx.x * tiles_per_wg, t1 = min(tiles_total, t0 + tiles_per_wg);
+  // tile t+1 is fetched into registers while tile t is multiplied
+  float4 zreg[SP_M / 16];
+  float preg[6];
+  const int zq = tid & 15, zr0 = tid >> 4;
+  auto fetch = [&](long t) {
+    long r_ = t;
+    const int bx = (int)(r_ % px);
+    r_ /= px;
+    const int by = (int)(r_ % py);
+    r_ /= py;
+    const int bz = (int)(r_ % pz);
+    const int b = (int)(r_ / pz);
+    const int z0 = bz * SP_Z, y0 = by * SP_Y, x0 = bx * SP_X;
+#pragma unroll
+    for (int pss = 0; pss < SP_M / 16; ++pss) {  // dZ tile: 128 voxels x 64 channels
+      const int r = zr0 + 16 * pss;
+      const int z = z0 + (r >> 5), y = y0 + ((r >> 3) & 3), x = x0 + (r & 7);
+      zreg[pss] = (z < D && y < H && x < W) ? *(const float4*)(dZ + ((((long)b * D + z) * H + y) * W + x) * 64 + zq * 4)
+                                           : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // input patch with its 3-voxel halo
+      const int e = tid + 256 * k;
+      const int pzz = e / 140, rem = e - pzz * 140, pyy = rem / 14, pxx = rem - pyy * 14;
+      const int z = z0 + pzz - 3, y = y0 + pyy - 3, x = x0 + pxx - 3;
+      preg[k] = (e < 1400 && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    ? X[(((long)b * D + z) * H + y) * W + x]
+                    : 0.f;
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (long t = t0; t < t1; ++t) {
+    __syncthreads();  // previous tile's fragment reads are done
+#pragma unroll
+    for (int pss = 0; pss < SP_M / 16; ++pss) {
+      float* d = Ys + (zr0 + 16 * pss) * SWG_LDY + zq * 4;
+      d[0] = zreg[pss].x;
+      d[1] = zreg[pss].y;
+      d[2] = zreg[pss].z;
+      d[3] = zreg[pss].w;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int e = tid + 256 * k;
+      const int pzz = e / 140, rem = e - pzz * 140, pyy = rem / 14, pxx = rem - pyy * 14;
+      if (e < 1400) patch[pzz * SWG_PP + pyy * SWG_PR + pxx] = preg[k];
+    }
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 4
+    for (int kk = 0; kk < SP_M / 2; ++kk) {
+      const int v = 2 * kk + half;  // voxel of this half-wave: (z, y, x) = (v >> 5, (v >> 3) & 3, v & 7)
+      const int vbase = (v >> 5) * SWG_PP + ((v >> 3) & 3) * SWG_PR + (v & 7);
+      float fa[2], fb[3];
+      fa[0] = Ys[v * SWG_LDY + col];
+      fa[1] = Ys[v * SWG_LDY + 32 + col];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fb[j] = patch[tval[j] ? vbase + toff[j] : SWG_PATCH];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (wave + 4 * j >= 11) continue;
+    const int tap = 32 * (wave + 4 * j) + col;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (tap < 343) atomicAdd(dW + (long)co * kpad + tap, acc[i][j][r]);
+      }
+  }
+}
+
 // ---------------------------------------------------------------- stem forward on the 4x4x1 matrix-core instruction
 // The stem (1 -> 64 channels, 7^3 taps) as a GEMM has K = 343 taps of a single-channel volume: the generic kernel
 // gathers its A tile element by element.  With v_mfma_f32_4x4x1_16b_f32 (16 blocks of a 4x4 outer product; row i =
@@ -1329,6 +1445,16 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
   const IgemmGeom& g = p.wgrad;
   const int Kc = p.stem ? g.kpt * BK : g.Cin;
   HP_CHECK_HIP(hipMemsetAsync(dw_packed, 0, sizeof(float) * hp_conv3d_packed_weight_elems(d), st));
+  if (p.stem && p.planes == 0 && d->Cout == 64) {
+    const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
+    const long tiles = (long)d->B * pz * py * px;
+    const int per_wg = (int)std::max<long>(1, (tiles + 1023) / 1024);  // ~1024 workgroups, 2 resident per CU
+    HP_PROF("conv_wgrad", st);
+    hipLaunchKernelGGL(k_stem_wgrad_full, dim3((unsigned)((tiles + per_wg - 1) / per_wg)), dim3(256), 0, st, x, dy, dw_packed, d->Di,
+                       d->Hi, d->Wi, pz, py, px, tiles, per_wg, Kc);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+  }
   const int TT = (g.Nout >= 128 && Kc >= 128) ? 128 : 64;
   // 64-wide tiles of a plain 3^3 convolution: 4 taps per block share the staged dY tile
   const bool multitap = !p.stem && TT == 64 && g.mode == MODE_CONV && g.k == 3;
