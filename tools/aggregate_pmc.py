@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-FAMILY = [("k_wgrad", "conv_wgrad"), ("k_stem_dgrad", "conv_stem_dgrad"), ("k_igemm", "conv_igemm(fwd+dgrad)"),
+FAMILY = [("k_wgrad", "conv_wgrad"), ("k_stem_wgrad", "conv_wgrad"), ("k_stem_fwd", "conv_igemm(fwd+dgrad)"), ("k_stem_dgrad", "conv_stem_dgrad"), ("k_igemm", "conv_igemm(fwd+dgrad)"),
           ("k_bn_", "batchnorm"), ("k_stem_bwd", "stem_bn_pool"), ("k_bn_relu_pool3", "stem_bn_pool"), ("k_dconv3_wgrad", "dconv3_wgrad"), ("k_dconv3", "dconv3_fwd+dgrad"),
           ("k_maxpool3", "maxpool3"), ("k_axis_", "lct"), ("at::native", "aten(autograd adds, Adam)")]
 
