@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "hp_internal.h"
@@ -1387,11 +1388,13 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
     const int zchunk = (d->Di + zsplit - 1) / zsplit;
     zsplit = (d->Di + zchunk - 1) / zchunk;
     const size_t lds = sizeof(float) * (343 * 64 + 8 * SF_PLANE + 4 * 64 * 33);
-    static bool attr_set = false;
-    if (!attr_set) {
-      HP_CHECK_HIP(hipFuncSetAttribute((const void*)k_stem_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
+    // opt in to > 64 KB of dynamic LDS once per process (idempotent; std::call_once keeps concurrent callers safe)
+    static std::once_flag lds_once;
+    static hipError_t lds_rc = hipSuccess;
+    std::call_once(lds_once, [&] {
+      lds_rc = hipFuncSetAttribute((const void*)k_stem_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    HP_CHECK_HIP(lds_rc);
     HP_PROF("conv_igemm_stem", st);
     hipLaunchKernelGGL(k_stem_fwd_mfma, dim3((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)d->B), dim3(256), lds, st, x, w_fwd,
                        y, stats, d->Di, d->Hi, d->Wi, p.fwd.kpt * BK, tiles_x, tiles_y, zchunk);
