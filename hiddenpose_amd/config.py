@@ -66,7 +66,7 @@ def get_cfg_defaults() -> CfgNode:
         NAME="nlospose", DNUM=1, BASEDIM=1, BIN_LEN=0.01, WALL_SIZE=2.0, IN_CHANNELS=1, OUT_CHANNELS=1,
         TIME_SIZE=512, IMAGE_SIZE=[256, 256], HEATMAP_SIZE=[64, 64, 64], MODE="lct",
         COORD_REPRESENTATION="3DHeatmap", NUM_JOINTS=24, BACKBONE="posenet3d_50",
-        PRETRAIN_AUTOENCODER=False, PRETRAIN_AUTOENCODER_PATH="./lib/nlos_unet.pth",
+        PRETRAIN_AUTOENCODER=False, PRETRAIN_AUTOENCODER_PATH="./lib/nlos_unet.pth", LOCATION="",
         # not a reference key: arithmetic of the regressor's convolution GEMMs, "fp32" (default, exact) or
         # "bf16" (bf16 operands / fp32 accumulation; LCT, U-Net, norms and losses stay fp32)
         CONV_PRECISION="fp32",
@@ -77,6 +77,7 @@ def get_cfg_defaults() -> CfgNode:
                       BEGIN_EPOCH=0, END_EPOCH=15)
     c.TEST = CfgNode(TYPE="pose_v2", BATCH_SIZE=2)
     c.LOSS = CfgNode(TYPE="L2JointLocationLoss")
+    c.RESULT = CfgNode(FINAL_OUTPUT_DIR="./checkpoints")
     return c
 
 

@@ -76,3 +76,50 @@ def predict_joints(model, meas, cfg):
     output, _ = model(meas)
     hm = cfg.DATASET.HEATMAP_SIZE
     return softmax_integral_tensor(output, cfg.DATASET.NUM_JOINTS, True, hm[0], hm[1], hm[2])
+
+
+def train_epoch(cfg, train_loader, model, criterion, voxel_criterion, optimizer, epoch, output_dir, writer, begin_time,
+                save_model_dir, lr_scheduler, reducer=None, max_steps=None):
+    """One epoch with the call signature of utils/train_epoch.py:20-104 (positional order as train.py:162 passes it).
+    Per batch: forward, L2Joint + BCEDice loss, zero_grad, backward, step; a checkpoint dict every 10000 global
+    iterations (:78-90) and the running 100-iteration loss (:92-97).  The reference's per-step `loss.item()` print,
+    `np.savetxt` and matplotlib dumps are not reproduced: the loss is accumulated on the device and read back once
+    per 100 iterations, so the loop never stalls the GPU.  `writer` may be None.  Returns the mean loss of the epoch."""
+    import os
+    import time
+
+    model.train()
+    device = next(model.parameters()).device
+    n_batches = len(train_loader)
+    total_step = (cfg.TRAIN.END_EPOCH - cfg.TRAIN.BEGIN_EPOCH) * n_batches
+    window = torch.zeros((), dtype=torch.float32, device=device)
+    epoch_sum = torch.zeros((), dtype=torch.float32, device=device)
+    t_window = epoch_t0 = time.time()
+    steps = 0
+    for step, (meas, vol, target_joints, _ids) in enumerate(train_loader):
+        if max_steps is not None and step >= max_steps:
+            break
+        global_iter_num = epoch * n_batches + step + 1
+        meas = torch.as_tensor(meas).to(device=device, dtype=torch.float32)
+        vol = torch.as_tensor(vol).to(device=device, dtype=torch.float32)
+        target_joints = torch.as_tensor(target_joints).to(device=device, dtype=torch.float32)  # (B, 24, 3)
+        loss, _, _ = train_step(model, criterion, voxel_criterion, optimizer, meas, vol, target_joints, reducer)
+        window += loss
+        epoch_sum += loss
+        steps += 1
+        if global_iter_num % 10000 == 0:
+            os.makedirs(save_model_dir, exist_ok=True)
+            torch.save(checkpoint_dict(model, optimizer, lr_scheduler, epoch, global_iter_num),
+                       os.path.join(save_model_dir, f"NlosPose_dict_iter{global_iter_num}.pth"))
+        if global_iter_num % 100 == 0:
+            mean100 = float(window) / 100.0
+            window.zero_()
+            now = time.time()
+            print(f"global iter is {global_iter_num}, loss is {mean100}, iter100 time is {now - t_window}, "
+                  f"{global_iter_num / max(total_step, 1) * 100}%")
+            t_window = now
+            if writer is not None:
+                writer.add_scalar("Train Loss", mean100, global_iter_num)
+    if writer is not None:
+        writer.add_scalar("batch_time", time.time() - epoch_t0, epoch)
+    return float(epoch_sum) / max(steps, 1)

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Evaluation entry point with the reference's command line (test.py:29-242):
+
+    python test.py --test test_pose_v2 --model ckpt.pth --data /path/to/pose_v2_noise
+    python test.py --test test_realdata --model ckpt.pth --realdata data/lct256_human.mat
+
+eval-mode forward + soft-argmax decode.  test_pose_v2 walks the test split in batches of TEST.BATCH_SIZE, writes
+`./test_results/joints/preds_<id>.txt` / `gt_<id>.txt` (24 x 3, voxel units of the 64^3 heat-map; the reference
+renders them to figures) and prints the MPJPE; test_realdata runs a measured `.mat` volume duplicated to batch 2
+as test.py:183-201 does."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from hiddenpose_amd import testing as hpt
+from hiddenpose_amd.cli import build_config, load_checkpoint, parse_args
+from hiddenpose_amd.criterion import softmax_integral_tensor
+from hiddenpose_amd.NlosPose import NlosPose
+from hiddenpose_amd.train_epoch import build_training, seed_everything
+
+
+def _decode(model, cfg, meas):
+    output, feature = model(meas)
+    hm = cfg.DATASET.HEATMAP_SIZE
+    return softmax_integral_tensor(output, cfg.DATASET.NUM_JOINTS, True, hm[0], hm[1], hm[2]), feature
+
+
+def main(argv=None):
+    seed_everything(410)
+    args = parse_args(argv)
+    cfg = build_config(args)
+    cfg.defrost()
+    cfg.PHASE = "test"
+    cfg.DATASET.PHASE = "test"
+    cfg.freeze()
+    dev = torch.device("cuda", cfg.DEVICE)
+    torch.cuda.set_device(dev)
+    model = NlosPose(cfg).to(dev)
+    _, _, optimizer, lr_scheduler = build_training(cfg, model)
+    kind = cfg.TEST.TYPE
+    if kind in ("test_realdata", "test_pose_v2", "test_fk"):
+        load_checkpoint(cfg.MODEL.LOCATION, model, optimizer, lr_scheduler, device=str(dev))
+    model.eval()
+    out_dir = "./test_results/joints"
+    os.makedirs(out_dir, exist_ok=True)
+    nj = cfg.DATASET.NUM_JOINTS
+    result = {}
+    with torch.no_grad():
+        if kind == "test_realdata":
+            from hiddenpose_amd.loadrealdata import load_realdata
+
+            meas = load_realdata(args.realdata, device=dev)                      # (t, w, h)
+            meas = meas[None, None].repeat(2, 1, 1, 1, 1).contiguous().float()    # test.py:190
+            preds, _ = _decode(model, cfg, meas)
+            name = os.path.splitext(os.path.basename(args.realdata))[0]
+            np.savetxt(os.path.join(out_dir, f"pred_real_joints_{name}.txt"), preds[0].reshape(nj, 3).cpu().numpy())
+            result["preds"] = preds[0].reshape(nj, 3).cpu().numpy()
+        elif kind == "test_pose_v2":
+            from hiddenpose_amd.nlos_pose_dataloader import NlosPoseDataset
+            from train import _collate
+
+            data = NlosPoseDataset(cfg, cfg.DATASET.TEST_PATH, device=dev)
+            loader = DataLoader(data, batch_size=cfg.TEST.BATCH_SIZE, shuffle=False, num_workers=0, collate_fn=_collate)
+            errs = []
+            for meas, _vol, target_joints, ids in loader:
+                if meas.shape[0] == 1:  # the reference always evaluates pairs (test.py:155)
+                    meas = meas.repeat(2, 1, 1, 1, 1)
+                preds, _ = _decode(model, cfg, meas.to(dev))
+                gt = target_joints.reshape(target_joints.shape[0], -1).to(dev)
+                for i, pid in enumerate(ids):
+                    np.savetxt(os.path.join(out_dir, f"preds_{pid}.txt"), preds[i].reshape(nj, 3).cpu().numpy())
+                    np.savetxt(os.path.join(out_dir, f"gt_{pid}.txt"), gt[i].reshape(nj, 3).cpu().numpy())
+                    errs.append(hpt.mpjpe(preds[i:i + 1].cpu(), gt[i:i + 1].cpu()))
+                if args.max_steps is not None and len(errs) >= args.max_steps * cfg.TEST.BATCH_SIZE:
+                    break
+            result["mpjpe_voxels"] = float(np.mean(errs)) if errs else float("nan")
+            print(f"MPJPE over {len(errs)} samples: {result['mpjpe_voxels']:.4f} heat-map voxels "
+                  f"({result['mpjpe_voxels'] * 31.25:.2f} mm)")
+        else:
+            raise SystemExit(f"TEST.TYPE {kind!r}: use --test test_pose_v2 or --test test_realdata")
+    print("finished")
+    return result
+
+
+if __name__ == "__main__":
+    main()

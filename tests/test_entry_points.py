@@ -1,0 +1,83 @@
+"""Row H of the scope table: the callers.  Command line and config patching of train.py / test.py (CPU), and one
+pass dataset -> train_epoch -> checkpoint -> reload -> eval decode on synthetic files (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def test_command_line_and_config_patching():
+    from hiddenpose_amd.cli import build_config, parse_args
+
+    a = parse_args(["--data", "/d", "--model", "/m.pth", "--test", "test_pose_v2", "--log", "/l", "--device", "0",
+                    "--PHASE", "continue_train"])
+    cfg = build_config(a)
+    # train.py:77-86: every run is patched to the 128^3 shape with the 4x coarser time bin
+    assert cfg.MODEL.TIME_SIZE == 128 and cfg.MODEL.IMAGE_SIZE == [128, 128] and abs(cfg.MODEL.BIN_LEN - 0.04) < 1e-12
+    assert cfg.DATASET.TRAIN_PATH == "/d" and cfg.MODEL.LOCATION == "/m.pth" and cfg.TEST.TYPE == "test_pose_v2"
+    assert cfg.LOG_DIR == "/l" and cfg.PHASE == "continue_train"
+    assert cfg.TRAIN.LR_STEP == [2, 4, 13] and cfg.TRAIN.LR_FACTOR == 0.2 and cfg.TRAIN.LR == 0.001
+    with pytest.raises(AttributeError):
+        cfg.MODEL.TIME_SIZE = 64  # frozen, like the yacs node
+
+
+def test_entry_points_import_without_a_gpu():
+    import importlib
+
+    for name in ("train", "test"):
+        m = importlib.import_module(name)
+        assert callable(m.main)
+
+
+@pytest.mark.gpu
+def test_dataset_to_train_epoch_to_checkpoint_to_eval(tmp_path):
+    from scipy.io import savemat
+
+    import ingest_oracle as io
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.cli import load_checkpoint
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.NlosPose import NlosPose
+    from hiddenpose_amd.nlos_pose_dataloader import NlosPoseDataset
+    from hiddenpose_amd.train_epoch import build_training, checkpoint_dict, predict_joints, train_epoch
+    from train import _collate
+
+    base = tmp_path / "pose0" / "train"
+    for sub in ("meas", "vol", "joints"):
+        (base / sub).mkdir(parents=True)
+    g = np.random.Generator(np.random.PCG64(9))
+    for k in range(2):
+        (base / "meas" / f"p{k}.hdr").write_bytes(io.rgbe_write(hpt.synthetic_rgbe(600, 64, 64, seed=20 + k), rle=False))
+        savemat(str(base / "vol" / f"p{k}.mat"), {"vol": (g.random((256, 64, 64)) < 0.02).astype(np.float32)})
+        np.savetxt(str(base / "joints" / f"p{k}.joints"), g.random((24, 3)) * 0.2 - 0.1)
+    cfg = make_cfg(128, 32)            # 600 x 64 x 64 pixels -> (128, 32, 32) after the ingest pyramid
+    cfg.TRAIN.END_EPOCH = 1
+    ds = NlosPoseDataset(cfg, str(tmp_path))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, collate_fn=_collate)
+    model = NlosPose(cfg)
+    hpt.fill_module(model)
+    model = model.cuda()
+    before = model.pose_net.conv1.weight.detach().clone()
+    criterion, voxel_criterion, optimizer, sched = build_training(cfg, model)
+    sched.step()
+    mean_loss = train_epoch(cfg, loader, model, criterion, voxel_criterion, optimizer, 0, str(tmp_path), None, 0.0,
+                            str(tmp_path / "ck"), sched)
+    assert np.isfinite(mean_loss)
+    assert not torch.equal(before, model.pose_net.conv1.weight.detach())
+    path = tmp_path / "NlosPose_final_dict_0.pth"
+    torch.save(checkpoint_dict(model, optimizer, sched, 0), str(path))
+    fresh = NlosPose(cfg).cuda()
+    _, _, opt2, sched2 = build_training(cfg, fresh)
+    ck = load_checkpoint(str(path), fresh, opt2, sched2)
+    assert set(ck) >= {"model_state_dict", "optimizer_state_dict", "lr_scheduler", "epoch"} and ck["epoch"] == 0
+    meas, _, _, _ = next(iter(loader))
+    a = predict_joints(model, meas.cuda(), cfg)
+    b = predict_joints(fresh, meas.cuda(), cfg)
+    # (the split soft-argmax adds its 32 partial sums with fp32 atomics: equal up to summation order)
+    assert a.shape == (2, 72) and torch.allclose(a, b, rtol=1e-5, atol=1e-5) and torch.isfinite(a).all()
