@@ -7,7 +7,7 @@
 eval-mode forward + soft-argmax decode.  test_pose_v2 walks the test split in batches of TEST.BATCH_SIZE, writes
 `./test_results/joints/preds_<id>.txt` / `gt_<id>.txt` (24 x 3, voxel units of the 64^3 heat-map; the reference
 renders them to figures) and prints the MPJPE; test_realdata runs a measured `.mat` volume duplicated to batch 2
-as test.py:183-201 does."""
+as test.py:183-201 does; test_fk runs every f-k capture `.mat` under --data (test.py:141-170)."""
 from __future__ import annotations
 
 import os
@@ -80,8 +80,26 @@ def main(argv=None):
             result["mpjpe_voxels"] = float(np.mean(errs)) if errs else float("nan")
             print(f"MPJPE over {len(errs)} samples: {result['mpjpe_voxels']:.4f} heat-map voxels "
                   f"({result['mpjpe_voxels'] * 31.25:.2f} mm)")
+        elif kind == "test_fk":
+            # test.py:141-170: f-k captures (h, w, t) .mat files: two pair-averages along t, bins 64..191, batch of 2
+            from scipy.io import loadmat
+
+            result["preds"] = {}
+            for fname in sorted(os.listdir(cfg.DATASET.TEST_PATH)):
+                if not fname.endswith(".mat"):
+                    continue
+                raw = torch.from_numpy(loadmat(os.path.join(cfg.DATASET.TEST_PATH, fname))["meas"]).to(dev).float()
+                x = raw
+                for _ in range(2):
+                    x = (x[:, :, ::2] + x[:, :, 1::2]) / 2
+                x = x[:, :, 64:64 + 128].permute(2, 0, 1).contiguous()            # 'h w t -> t h w'
+                meas = x[None, None].repeat(2, 1, 1, 1, 1).contiguous()
+                preds, _ = _decode(model, cfg, meas)
+                name = os.path.splitext(fname)[0]
+                np.savetxt(os.path.join(out_dir, f"pred_fk_joints_{name}.txt"), preds[0].reshape(nj, 3).cpu().numpy())
+                result["preds"][name] = preds[0].reshape(nj, 3).cpu().numpy()
         else:
-            raise SystemExit(f"TEST.TYPE {kind!r}: use --test test_pose_v2 or --test test_realdata")
+            raise SystemExit(f"TEST.TYPE {kind!r}: use --test test_pose_v2, test_realdata or test_fk")
     print("finished")
     return result
 
