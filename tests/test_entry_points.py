@@ -81,3 +81,25 @@ def test_dataset_to_train_epoch_to_checkpoint_to_eval(tmp_path):
     b = predict_joints(fresh, meas.cuda(), cfg)
     # (the split soft-argmax adds its 32 partial sums with fp32 atomics: equal up to summation order)
     assert a.shape == (2, 72) and torch.allclose(a, b, rtol=1e-5, atol=1e-5) and torch.isfinite(a).all()
+
+
+@pytest.mark.gpu
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """Twelve Adam steps of the HIP path on one fixed 128^3 batch with the reference's initialisation and
+    hyper-parameters: the L2Joint + BCEDice loss must fall (gradients of every stage point the right way)."""
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.NlosPose import NlosPose
+    from hiddenpose_amd.train_epoch import build_training, seed_everything, train_step
+
+    seed_everything(410)
+    cfg = make_cfg(128, 128)
+    model = NlosPose(cfg).cuda().train()
+    criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+    meas = hpt.synthetic_meas(2, 128, 128, "transient", seed=1).cuda()
+    vol = hpt.synthetic_vol(2, 128, 128, seed=2).cuda()
+    joints = hpt.synthetic_joints(2, 64, seed=3).cuda()
+    losses = [float(train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints)[0]) for _ in range(12)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert min(losses[6:]) < min(losses[:3]), losses
