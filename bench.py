@@ -318,13 +318,20 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal hook (single-GPU boxes): HP_DIST_BACKEND=gloo HP_SHARE_GPU=1 runs all ranks on cuda:0 over gloo
+    backend = os.environ.get("HP_DIST_BACKEND", "nccl")
+    if os.environ.get("HP_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from hiddenpose_amd import _lib
     from hiddenpose_amd import testing as hpt
