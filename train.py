@@ -3,6 +3,7 @@
 
     python train.py --data /path/to/pose_v2_noise [--PHASE train|continue_train --model ckpt.pth --log ./log]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --data ...   # data parallel
+    (under the launcher write --log=DIR: a bare "--log" is ambiguous for torch.distributed.run's own parser)
 
 seed 410; NlosPose at 128 x 128 x 128; NlosPoseDataset with the per-sample ingest on the GPU; Adam(lr 1e-3);
 MultiStepLR([2, 4, 13], 0.2) stepped BEFORE each epoch (train.py:193); L2Joint + BCEDice; a checkpoint dict per
@@ -33,7 +34,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(args.device)))
-    args.device = local if world > 1 else args.device
+    args.device = (0 if os.environ.get("HP_SHARE_GPU") else local) if world > 1 else args.device
     cfg = build_config(args)
     torch.cuda.set_device(cfg.DEVICE)
     reducer = None
@@ -44,7 +45,11 @@ def main(argv=None):
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", cfg.DEVICE))
+        backend = os.environ.get("HP_DIST_BACKEND", "nccl")  # "gloo" only to rehearse on a box without several GPUs
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", cfg.DEVICE))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     model = NlosPose(cfg).to(torch.device("cuda", cfg.DEVICE))
     if rank == 0:
