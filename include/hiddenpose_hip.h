@@ -95,7 +95,7 @@ int hp_lct_plan_get_invpsf(const hp_lct_plan* plan, float* invpsf_re, float* inv
  * hp_conv3d_* replace nn.Conv3d / nn.ConvTranspose3d forward and both gradients
  * (posenet3d_50.py:9-24 conv3x3x3/conv1x1x1, :176-181 stem, :129-132 deconv).
  * Supported: Conv3d k in {1,3,7}, stride 1|2 (k7: the 1-channel stride-1 stem),
- * Cin % 32 == 0 otherwise; ConvTranspose3d k4 s2 p1.
+ * Cin % 4 == 0 otherwise (stride-2 data gradients and ConvTranspose3d k4 s2 p1: channels % 32 == 0).
  * Weights are used in a packed K-contiguous layout ([tap][Cout][Cin]; for the
  * data gradient [tap][Cin][Cout]) produced by hp_conv3d_pack_weight from the
  * torch layout and converted back for gradients by hp_conv3d_unpack_wgrad.
@@ -173,7 +173,7 @@ int hp_layout_transpose(const float* in, float* out, int B, long V, int C, int t
  * FeatureExtraction / ResConv3D (models/feature_extraction.py:147-158,167,228-256;
  * replicate_pad = 1 for the ReplicationPad3d(1)+Conv3d pairs, 0 for the zero-padded box
  * filter) and UNet3d's DoubleConv convolutions (unet/unet3d.py:15-23).
- * Weights in the torch layout (Cout, Cin, 3, 3, 3).  Cout in {1,4,8,16,32,64}.
+ * Weights in the torch layout (Cout, Cin, 3, 3, 3); any channel counts (4-wide matrix-core blocks, padded).
  * ---------------------------------------------------------------------- */
 int hp_dconv3_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int D,
                       int H, int W, int replicate_pad, void* stream);
