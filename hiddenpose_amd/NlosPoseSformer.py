@@ -65,15 +65,13 @@ class _FeedForward(nn.Module):
 _LINEAR_PRECISION = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}  # HP_PRECISION_*
 
 
-def _linear(x2d, weight, bias, precision=0):
-    """y = x @ W^T + b through hp_conv3d_forward (k = 1).  x2d (M, K) contiguous."""
-    L = _lib.lib()
+def _linear(x2d, weight, bias, precision=0, residual=None):
+    """y = x @ W^T + b (+ residual, written in place into `residual`) through hp_linear_forward.  x2d (M, K) contiguous."""
     M, K = x2d.shape
     N = weight.shape[0]
-    y = torch.empty(M, N, dtype=torch.float32, device=x2d.device)
-    desc = _lib.ConvDesc(1, 1, 1, M, K, N, 1, 1, 0, 0, precision)
-    _lib.check(L.hp_conv3d_forward(C.byref(desc), x2d.data_ptr(), weight.data_ptr(), _lib.ptr(bias), y.data_ptr(), None,
-                                   _lib.current_stream_handle(x2d.device)), "hp_conv3d_forward(linear)")
+    y = residual if residual is not None else torch.empty(M, N, dtype=torch.float32, device=x2d.device)
+    _lib.check(_lib.lib().hp_linear_forward(x2d.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), y.data_ptr(),
+                                            M, K, N, precision, _lib.current_stream_handle(x2d.device)), "hp_linear_forward")
     return y
 
 
@@ -149,16 +147,14 @@ class NlosPoseSformer(nn.Module):
                            "hp_sformer_qkv_prepare")
                 _lib.check(L.hp_sformer_attention(q.data_ptr(), k.data_ptr(), k0.data_ptr(), v.data_ptr(), att.data_ptr(), b, heads, dh, ntok, nj,
                                                   n, f, aprec, aws.data_ptr(), st), "hp_sformer_attention")
-                proj = _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias, prec)
-                _lib.check(L.hp_leaky_add_forward(x.data_ptr(), proj.data_ptr(), x.data_ptr(), x.numel(), 1.0, st), "residual add")
+                _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias, prec, residual=x.view(rows, dim))
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, ff.norm.weight.data_ptr(),
                                                   ff.norm.bias.data_ptr(), ff.norm.eps, 0, 0, st), "hp_layernorm_forward")
                 u = _linear(h.view(rows, dim), ff.fn.net[0].weight, ff.fn.net[0].bias, prec)
                 hid = ff.fn.net[3].weight.shape[1]
                 g = torch.empty(rows, hid, dtype=torch.float32, device=dev)
                 _lib.check(L.hp_geglu_forward(u.data_ptr(), g.data_ptr(), rows, hid, st), "hp_geglu_forward")
-                d = _linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, prec)
-                _lib.check(L.hp_leaky_add_forward(x.data_ptr(), d.data_ptr(), x.data_ptr(), x.numel(), 1.0, st), "residual add")
+                _linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, prec, residual=x.view(rows, dim))
             jt = torch.empty(b * nj, dim, dtype=torch.float32, device=dev)
             _lib.check(L.hp_layernorm_forward(x.data_ptr(), jt.data_ptr(), b * nj, dim, self.to_out[0].weight.data_ptr(),
                                               self.to_out[0].bias.data_ptr(), self.to_out[0].eps, nj, ntok, st), "hp_layernorm_forward")

@@ -76,6 +76,7 @@ SIGNATURES = {
     "hp_softargmax_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "hp_bce_dice_forward": (_i, [_fp, _fp, C.c_long, C.c_float, _vp, _fp, _vp]),
     "hp_bce_dice_backward": (_i, [_fp, _fp, _vp, _fp, _fp, C.c_long, C.c_float, _vp]),
+    "hp_linear_forward": (_i, [_fp, _fp, _fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_sformer_patchify": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "hp_layernorm_forward": (_i, [_fp, _fp, C.c_long, _i, _fp, _fp, C.c_float, _i, C.c_long, _vp]),
     "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),

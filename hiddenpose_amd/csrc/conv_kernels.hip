@@ -1406,6 +1406,22 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
   return HP_OK;
 }
 
+extern "C" int hp_linear_forward(const float* x, const float* w, const float* bias, const float* addend, float* y, long M, int K,
+                                 int N, int precision, void* stream) {
+  HP_REQUIRE(x && w && y && M >= 1 && M < (1l << 31) && K >= 4 && N >= 1, "hp_linear_forward: bad argument");
+  hp_conv_desc d{1, 1, 1, (int)M, K, N, 1, 1, 0, 0, precision};
+  ConvPlan p;
+  int rc = make_plan(d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    HP_PROF("linear_fwd", st);
+    launch_igemm(p.fwd, 1, false, p.planes, x, w, bias, y, nullptr, addend, st);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
 extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                                        const float* addend, void* stream) {
   HP_REQUIRE(d && dy && w_dgrad && dx, "hp_conv3d_backward_data: null argument");

@@ -243,6 +243,11 @@ int hp_bce_dice_backward(const float* logit, const float* target, const double* 
  * hp_conv3d_forward with k = 1 (a 1x1x1 convolution over channels-last rows is a Linear; its packed
  * weight layout equals the torch (out, in) layout).
  * ---------------------------------------------------------------------- */
+/* nn.Linear with a fused residual: y (M, N) = x (M, K) @ w (N, K)^T + bias + addend.  bias and addend may be
+ * NULL; y may alias addend (x = x + f(x) in place, :117-118).  The implicit-GEMM kernel of hp_conv3d_forward with
+ * k = 1; precision as in hp_conv_desc. */
+int hp_linear_forward(const float* x, const float* w, const float* bias, const float* addend, float* y, long M, int K, int N,
+                      int precision, void* stream);
 /* rearrange 'b f c (h p1) (w p2) -> (b f h w) (p1 p2 c)'  (:104) */
 int hp_sformer_patchify(const float* video, float* tokens, int B, int frames, int C, int H, int W, int patch,
                         void* stream);
