@@ -199,3 +199,26 @@ def test_bf16_train_step_against_fp32_mode_128(capsys, prec):
     assert abs(jl1 / jl0 - 1) < max(tol_h, 2e-2)
     assert rel_l2(h1, h0) < tol_h
     assert min(cos.values()) > tol_c, cos
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_train_forward_odd_batches_vs_oracle(B):
+    """The reference indexes 3-element lists (B <= 3); the LCT packs volumes in pairs.  Odd batches (a lone volume
+    in the last pair) and batch 1 through the whole train-mode forward + loss against the oracle at T = N = 32."""
+    from oracle import nlospose_oracle as O
+
+    T = N = 32
+    cfg, model = make_model(T, N)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.train()
+    meas = hpt.synthetic_meas(B, T, N, seed=30 + B)
+    vol = hpt.synthetic_vol(B, T, N, seed=40 + B)
+    joints = hpt.synthetic_joints(B, T // 2, seed=50 + B)
+    criterion, voxel_criterion, _, _ = build_training(cfg, model)
+    loss, jl, vl, heat, refine = compute_loss(model, criterion, voxel_criterion, meas.cuda(), vol.cuda(), joints.cuda())
+    k = O.LCTConstants(N, T, cfg.MODEL.BIN_LEN)
+    ref_loss, _, _, ref_heat, ref_refine = O.train_loss(meas, vol, joints.reshape(B, -1), sd, k)
+    assert rel_l2(refine, ref_refine.detach().numpy()) < TOL
+    if B > 1:  # train-mode BatchNorm over a batch of one 1x1x1 map at layer4 is degenerate in the reference as well
+        assert rel_l2(heat, ref_heat.detach().numpy()) < TOL
+        assert abs(loss.item() / ref_loss.item() - 1) < TOL
