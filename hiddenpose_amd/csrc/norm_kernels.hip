@@ -42,7 +42,8 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, const float4* __restrict__ res,
                                                  float4* __restrict__ y, long n4, int C4, const float4* __restrict__ mean,
                                                  const float4* __restrict__ rstd, const float4* __restrict__ gamma,
-                                                 const float4* __restrict__ beta, int relu) {
+                                                 const float4* __restrict__ beta, int relu,
+                                                 unsigned char* __restrict__ mask_out) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
     const float4 v = z[i], m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
       o.w = fmaxf(o.w, 0.f);
     }
     y[i] = o;
+    // one byte per channel quad: which outputs are positive (the backward reads this instead of y: 1 B, not 16)
+    if (mask_out)
+      mask_out[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
   }
 }
 
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
                                                       int C4, const float4* __restrict__ mean,
                                                       const float4* __restrict__ rstd, int relu,
                                                       double* __restrict__ red, const float4* __restrict__ gamma,
-                                                      const float4* __restrict__ beta) {
+                                                      const float4* __restrict__ beta, const unsigned char* __restrict__ mask) {
   __shared__ float4 ssum[ET], sdot[ET];
   const int tid = threadIdx.x;
   const int lanes_per_row = C4 < ET ? C4 : ET;       // threads covering one row pass
@@ -103,7 +107,13 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
         const long i = row * C4 + cq;
         float4 g = dy[i];
         const float4 v = z[i];
-        if (relu) {
+        if (relu && mask) {
+          const unsigned mk = mask[i];
+          g.x = (mk & 1u) ? g.x : 0.f;
+          g.y = (mk & 2u) ? g.y : 0.f;
+          g.z = (mk & 4u) ? g.z : 0.f;
+          g.w = (mk & 8u) ? g.w : 0.f;
+        } else if (relu) {
           float4 yy;
           if (y) yy = y[i];
           else yy = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
@@ -514,13 +524,13 @@ extern "C" int hp_bn_eval_stats(const float* running_mean, const float* running_
 }
 
 extern "C" int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, int relu, void* stream) {
+                           const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream) {
   HP_REQUIRE(z && y && mean && rstd && gamma && beta && M > 0 && C > 0 && C % 4 == 0, "hp_bn_apply: bad argument");
   const long n4 = M * (C / 4);
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("bn_apply", st);
   hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)z, (const float4*)res, (float4*)y, n4,
-                     C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu);
+                     C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu, relu_mask);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
@@ -530,10 +540,12 @@ extern "C" size_t hp_bn_backward_workspace_bytes(int C) { return sizeof(double) 
 
 extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
                               const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask,
-                              int relu, int train, float* dgamma, float* dbeta, void* workspace, void* stream) {
+                              int relu, int train, float* dgamma, float* dbeta, const unsigned char* relu_mask,
+                              void* workspace, void* stream) {
   HP_REQUIRE(dy && z && dz && mean && rstd && gamma && workspace && M > 0 && C > 0 && C % 4 == 0,
              "hp_bn_backward: bad argument");
-  HP_REQUIRE(!relu || y || beta_for_mask, "hp_bn_backward: relu needs the forward output or beta to rebuild the mask");
+  HP_REQUIRE(!relu || y || relu_mask || beta_for_mask,
+             "hp_bn_backward: relu needs the forward output, its mask, or beta to rebuild the mask");
   // y may be NULL when there was no residual: the ReLU mask is then recomputed from z (bit-identical affine map)
   hipStream_t st = (hipStream_t)stream;
   double* red = (double*)workspace;
@@ -544,7 +556,7 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   const int C4 = C / 4;
   // g buffer: caller-provided g_out (residual units: g is also the gradient of the shortcut), or none at all when
   // pass 2 can rebuild the mask itself (no forward output given: mask from z, or no ReLU); dy must not alias dz then
-  const bool remask = !g_out && !y && dy != dz;
+  const bool remask = !g_out && !y && !relu_mask && dy != dz;
   float* gbuf = remask ? nullptr : g_out ? g_out : dz;
   {
     HP_PROF("bn_bwd_reduce", st);
@@ -552,7 +564,7 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
     const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(ET), 0, st, (const float4*)dy, (const float4*)y, (const float4*)z,
                        (float4*)gbuf, M, C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma,
-                       (const float4*)beta_for_mask);
+                       (const float4*)beta_for_mask, relu_mask);
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, M, C, mean, rstd, gamma, train, dgamma,
                      dbeta, ca, cb, cc);

@@ -424,11 +424,13 @@ class _ConvBnAct(torch.autograd.Function):
             y = torch.empty_like(z)
             if res is not None:
                 res = res.contiguous()
+            # with a residual the backward needs the sign pattern of the output: a byte per channel quad, written here
+            mask = (torch.empty(M * cout // 4, dtype=torch.uint8, device=x.device)
+                    if (res is not None and relu and any(ctx.needs_input_grad)) else None)
             _lib.check(L.hp_bn_apply(z.data_ptr(), _lib.ptr(res), y.data_ptr(), M, cout, mean.data_ptr(), rstd.data_ptr(),
-                                     gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, st), "hp_bn_apply")
-        # with a residual the ReLU mask needs the output; without, it is rebuilt from z (y is then not kept here,
-        # only by the consumer that reads it as its input)
-        ctx.save_for_backward(x, w, gamma, beta, z, y if res is not None else None, mean, rstd)
+                                     gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, _lib.ptr(mask), st), "hp_bn_apply")
+        # without a residual the mask is rebuilt from z; y itself is kept only by the consumer that reads it as input
+        ctx.save_for_backward(x, w, gamma, beta, z, mask, mean, rstd)
         ctx.cfg = (desc, relu, train, res is not None)
         ctx.links = (link_in, link_out)
         return y
@@ -436,7 +438,7 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x, w, gamma, beta, z, y, mean, rstd = ctx.saved_tensors
+        x, w, gamma, beta, z, mask, mean, rstd = ctx.saved_tensors
         desc, relu, train, has_res = ctx.cfg
         cout = z.shape[-1]
         M = z.numel() // cout
@@ -448,9 +450,9 @@ class _ConvBnAct(torch.autograd.Function):
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(gamma)
             ws = torch.empty(int(L.hp_bn_backward_workspace_bytes(cout)) // 4 + 2, dtype=torch.float32, device=x.device)
-            _lib.check(L.hp_bn_backward(dy.data_ptr(), _lib.ptr(y), z.data_ptr(), _lib.ptr(g), dz.data_ptr(), M, cout,
+            _lib.check(L.hp_bn_backward(dy.data_ptr(), None, z.data_ptr(), _lib.ptr(g), dz.data_ptr(), M, cout,
                                         mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
-                                        1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), st),
+                                        1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(mask), ws.data_ptr(), st),
                        "hp_bn_backward")
             link_in, link_out = ctx.links
             addend = None

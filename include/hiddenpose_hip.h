@@ -143,16 +143,19 @@ int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float mo
                          float* running_mean, float* running_var, void* stream);
 int hp_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
                      void* stream);
-/* y = act((z - mean) * rstd * gamma + beta [+ res]);  res may be NULL; relu = 0|1 */
+/* y = act((z - mean) * rstd * gamma + beta [+ res]);  res may be NULL; relu = 0|1.
+ * relu_mask (may be NULL): M*C/4 bytes, bit k of byte q = [y[4q + k] > 0] -- what the backward of a unit WITH a
+ * residual needs of y (1 byte instead of 16 per channel quad). */
 int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
-                const float* gamma, const float* beta, int relu, void* stream);
+                const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream);
 size_t hp_bn_backward_workspace_bytes(int C);
 /* g = dy * [y > 0] (stored to g_out if not NULL: gradient of the residual branch);
  * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL. */
-/* y may be NULL for a unit without residual: the ReLU mask is then rebuilt from z and beta_for_mask. */
+/* The ReLU mask comes from relu_mask (hp_bn_apply's byte mask) if given, else from y, else -- unit without a
+ * residual -- it is rebuilt from z and beta_for_mask. */
 int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask, int relu,
-                   int train, float* dgamma, float* dbeta, void* workspace, void* stream);
+                   int train, float* dgamma, float* dbeta, const unsigned char* relu_mask, void* workspace, void* stream);
 /* MaxPool3d(kernel 3, stride 2, padding 1) (posenet3d_50.py:184), channels-last. */
 int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
 int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H, int W,
