@@ -347,6 +347,38 @@ __global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restri
   }
 }
 
+// voxel index -> (b, d, h, w); shifts when all three extents are powers of two (runtime integer division costs ~40
+// instructions per quotient and these kernels do three per element)
+struct VoxDecode {
+  int D, H, W, sd, sh, sw;  // s* = log2 or -1
+};
+__host__ inline VoxDecode make_decode(int D, int H, int W) {
+  auto lg = [](int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+  };
+  VoxDecode q{D, H, W, lg(D), lg(H), lg(W)};
+  if (q.sd < 0 || q.sh < 0 || q.sw < 0) q.sd = q.sh = q.sw = -1;
+  return q;
+}
+__device__ __forceinline__ void decode_vox(const VoxDecode& q, long v, int& b, int& d, int& h, int& w) {
+  if (q.sw >= 0) {
+    w = (int)(v & (q.W - 1));
+    h = (int)((v >> q.sw) & (q.H - 1));
+    d = (int)((v >> (q.sw + q.sh)) & (q.D - 1));
+    b = (int)(v >> (q.sw + q.sh + q.sd));
+  } else {
+    long t = v;
+    w = (int)(t % q.W);
+    t /= q.W;
+    h = (int)(t % q.H);
+    t /= q.H;
+    d = (int)(t % q.D);
+    b = (int)(t / q.D);
+  }
+}
+
 // g[i] = [y_i > 0] * sum over the <= 8 windows o containing i of dp[o] * [y_i == p[o]]   (y recomputed from z)
 __device__ __forceinline__ float4 stem_pool_grad(const float4* __restrict__ p, const float4* __restrict__ dp, float4 y,
                                                  int b, int d, int h, int w, int c, int D, int H, int W, int C4) {
@@ -384,7 +416,7 @@ __global__ __launch_bounds__(ET) void k_stem_bwd_reduce(const float4* __restrict
                                                         const float4* __restrict__ dp, int B, int D, int H, int W, int C4,
                                                         const float4* __restrict__ sc, const float4* __restrict__ sh,
                                                         const float4* __restrict__ mean, const float4* __restrict__ rstd,
-                                                        double* __restrict__ red) {
+                                                        double* __restrict__ red, VoxDecode vq) {
   __shared__ float4 ssum[ET], sdot[ET];
   const int tid = threadIdx.x;
   const int cq = tid % C4, vrow = tid / C4, vpb = ET / C4;
@@ -392,13 +424,8 @@ __global__ __launch_bounds__(ET) void k_stem_bwd_reduce(const float4* __restrict
   const float4 a = sc[cq], s0 = sh[cq], mu = mean[cq], rs = rstd[cq];
   float4 s = make_float4(0, 0, 0, 0), dd = make_float4(0, 0, 0, 0);
   for (long v = (long)blockIdx.x * vpb + vrow; v < nvox; v += (long)gridDim.x * vpb) {
-    long t = v;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    t /= H;
-    const int d = (int)(t % D);
-    const int b = (int)(t / D);
+    int b, d, h, w;
+    decode_vox(vq, v, b, d, h, w);
     const float4 zv = z[v * C4 + cq];
     const float4 g = stem_pool_grad(p, dp, bn_relu4(zv, a, s0), b, d, h, w, cq, D, H, W, C4);
     s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
@@ -433,17 +460,13 @@ __global__ __launch_bounds__(ET) void k_stem_bwd_apply(const float4* __restrict_
                                                        const float4* __restrict__ dp, float4* __restrict__ dz, int B, int D,
                                                        int H, int W, int C4, const float4* __restrict__ sc,
                                                        const float4* __restrict__ sh, const float4* __restrict__ ca,
-                                                       const float4* __restrict__ cb, const float4* __restrict__ cc) {
+                                                       const float4* __restrict__ cb, const float4* __restrict__ cc,
+                                                       VoxDecode vq, int c4_shift) {
   const long total = (long)B * D * H * W * C4;
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    long t = i / C4;
-    const int w = (int)(t % W);
-    t /= W;
-    const int h = (int)(t % H);
-    t /= H;
-    const int d = (int)(t % D);
-    const int b = (int)(t / D);
+    const int c = c4_shift >= 0 ? (int)(i & (C4 - 1)) : (int)(i % C4);
+    int b, d, h, w;
+    decode_vox(vq, c4_shift >= 0 ? i >> c4_shift : i / C4, b, d, h, w);
     const float4 zv = z[i];
     const float4 g = stem_pool_grad(p, dp, bn_relu4(zv, sc[c], sh[c]), b, d, h, w, c, D, H, W, C4);
     const float4 a = ca[c], bq = cb[c], k = cc[c];
@@ -660,7 +683,7 @@ extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled
     const int vpb = ET / C4;
     hipLaunchKernelGGL(k_stem_bwd_reduce, dim3((unsigned)std::min<long>((nvox + vpb - 1) / vpb, 256 * 8)), dim3(ET), 0, st,
                        (const float4*)z, (const float4*)pooled, (const float4*)dpooled, B, D, H, W, C4, (const float4*)sc,
-                       (const float4*)sh, (const float4*)mean, (const float4*)rstd, red);
+                       (const float4*)sh, (const float4*)mean, (const float4*)rstd, red, make_decode(D, H, W));
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, nvox, C, mean, rstd, gamma, train, dgamma, dbeta,
                      ca, cb, cc);
@@ -668,7 +691,7 @@ extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled
     HP_PROF("stem_bn_pool_bwd_apply", st);
     hipLaunchKernelGGL(k_stem_bwd_apply, dim3(grid_for(nvox * C4)), dim3(ET), 0, st, (const float4*)z, (const float4*)pooled,
                        (const float4*)dpooled, (float4*)dz, B, D, H, W, C4, (const float4*)sc, (const float4*)sh, (const float4*)ca,
-                       (const float4*)cb, (const float4*)cc);
+                       (const float4*)cb, (const float4*)cc, make_decode(D, H, W), is_pow2(C4) ? ilog2(C4) : -1);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
