@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "hp_internal.h"
@@ -802,55 +803,103 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
     }
   };
   fetch_w(0);
-  for (int chunk = 0; chunk < 14; ++chunk) {
-    const int kd = chunk >> 1, kh0 = (chunk & 1) * 4, npair = (chunk & 1) ? 3 : 4;
-    __syncthreads();  // previous chunk: fragment reads, gather reads and patch updates are finished
+  // Fold bookkeeping, fixed per lane: cell (cyr, cx) of pass p = lane + 64 p; bit (gi * 7 + kw) of fmask[p] says
+  // whether term (gi, kw) of the cell lies inside the 4 x 8 (jy, jx) slice parked by this wave.
+  int fbase[2], fcell[2];
+  unsigned fmask[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = tid + h * CT;
-      const int tr = i >> 4, q = i & 15;
-      float* d = Bs + tr * SLD + q * 4;
-      d[0] = wv[h].x;
-      d[1] = wv[h].y;
-      d[2] = wv[h].z;
-      d[3] = wv[h].w;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cell = lane + 64 * pass;
+    const int cyr = cell / SR_X, cx = cell - cyr * SR_X;
+    unsigned m = 0u;
+    for (int gi = 0; gi < 4; ++gi)
+      for (int kw = 0; kw < 7; ++kw)
+        if (cell < 7 * SR_X && (unsigned)(cyr - gi) < (unsigned)SP_Y && (unsigned)(cx - kw) < (unsigned)SP_X) m |= 1u << (gi * 7 + kw);
+    fmask[pass] = m;
+    // staging index of term (gi, kw): jy = cyr - gi  =>  fbase + gi * (3 * SR_X * SG_KW) + kw; lanes without a cell read slot 0
+    fbase[pass] = cell < 7 * SR_X ? (cyr * SR_X + cx) * SG_KW : 0;
+    fcell[pass] = cyr * SR_X + cx;
+  }
+  // Software pipeline over the 14 tap chunks: while the matrix cores run chunk c (a dependent chain of 32 MFMAs
+  // on one accumulator tile), the same wave folds the P tile of chunk c-1 that it parked in its private staging
+  // array -- two LDS reads per MFMA slot -- so the fold costs no time of its own.  Workgroup barriers are needed
+  // only around the shared weight tile; the patch planes touched by the four waves within one step are distinct.
+  auto step = [&](auto mm_c, auto fold_c, int chunk) {
+    constexpr bool MM = decltype(mm_c)::value, FOLD = decltype(fold_c)::value;
+    const int pc = chunk - 1;  // the chunk being folded
+    const int kdp = pc >> 1, kh0p = (pc & 1) * 4;
+    const unsigned gmask = (pc & 1) ? 0x1FFFFFu : 0xFFFFFFFu;  // odd chunks hold 3 kh rows
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float fsum[2] = {0.f, 0.f}, fpend[2] = {0.f, 0.f};
+    float fa = 0.f, fb = 0.f;
+    if constexpr (MM) {
+      fa = ap[0];
+      fb = bp[0];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      float na = 0.f, nb = 0.f;
+      if constexpr (MM) {
+        if (kk + 1 < 32) {
+          na = ap[2 * (kk + 1)];
+          nb = bp[2 * (kk + 1)];
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+      }
+      if constexpr (FOLD) {
+        // slot kk issues the two staging reads of term (gi, kw) = (kk / 7, kk % 7) and adds those of slot kk - 1:
+        // every read is unconditional (always inside this wave's staging array), the select drops foreign terms
+        if (kk >= 1 && kk < 29) {
+          const int bit = kk - 1;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) fsum[pass] += ((fmask[pass] & gmask) >> bit & 1u) ? fpend[pass] : 0.f;
+        }
+        if (kk < 28) {
+          const int gi = kk / 7, kw = kk % 7;  // compile-time after unrolling
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) fpend[pass] = sw[fbase[pass] + gi * (3 * SR_X * SG_KW) + kw];
+        } else if (kk >= 29 && kk < 31) {
+          const int pass = kk - 29;
+          if (lane + 64 * pass < 7 * SR_X) patch[((wave + kdp) * SR_Y + kh0p) * SR_X + fcell[pass]] += fsum[pass];
+        }
+      }
+      if constexpr (MM) {
+        fa = na;
+        fb = nb;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MM) {
+      // park P: register r is voxel (jy = r>>2, jx = (r&3) + 4*half) of this wave's z slice
+      const int npair = (chunk & 1) ? 3 : 4;
+      if (kw_l < 7 && gi_l < npair) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sw[sw_lane + ((r >> 2) * SR_X + (r & 3)) * SG_KW] = acc[r];
+      }
+    }
+  };
+  for (int chunk = 0; chunk <= 14; ++chunk) {
+    __syncthreads();  // every wave is through the fragment reads of the previous weight tile and its patch update
+    if (chunk < 14) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = tid + h * CT;
+        const int tr = i >> 4, q = i & 15;
+        float* d = Bs + tr * SLD + q * 4;
+        d[0] = wv[h].x;
+        d[1] = wv[h].y;
+        d[2] = wv[h].z;
+        d[3] = wv[h].w;
+      }
     }
     __syncthreads();
     if (chunk + 1 < 14) fetch_w(chunk + 1);
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk], bp[2 * kk], acc, 0, 0, 0);
-    // park P: register r is voxel (jy = r>>2, jx = (r&3) + 4*half) of this wave's z slice
-    if (kw_l < 7 && gi_l < npair) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sw[sw_lane + ((r >> 2) * SR_X + (r & 3)) * SG_KW] = acc[r];
-    }
-    __syncthreads();
-    // fold: cell (cyr in 0..6, cx in 0..13) of plane cz = wave + kd
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int cell = lane + 64 * pass;
-      if (cell < 7 * SR_X) {
-        const int cyr = cell / SR_X, cx = cell - cyr * SR_X;
-        float sum = 0.f;
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-          const int jy = cyr - gi;
-          if (gi < npair && jy >= 0 && jy < SP_Y) {
-            const float* sp = sw + ((gi * SP_Y + jy) * SR_X + cx) * SG_KW;
-#pragma unroll
-            for (int kw = 0; kw < 7; ++kw) {
-              const int jx = cx - kw;
-              if (jx >= 0 && jx < SP_X) sum += sp[kw];
-            }
-          }
-        }
-        patch[((wave + kd) * SR_Y + kh0 + cyr) * SR_X + cx] += sum;
-      }
-    }
+    if (chunk == 0) step(std::true_type{}, std::false_type{}, chunk);
+    else if (chunk < 14) step(std::true_type{}, std::true_type{}, chunk);
+    else step(std::false_type{}, std::true_type{}, chunk);
   }
   __syncthreads();
   for (int i = tid; i < SR_N; i += CT) {

@@ -12,6 +12,6 @@ dx = torch.empty_like(x)
 for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5):
-        L.hp_conv3d_backward_data(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), ops._stream(x))
+        L.hp_conv3d_backward_data(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, ops._stream(x))
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print(f"stem dgrad B={B} 128^3: {dt*1e3:.2f} ms  -> {2*B*D*H*W*343*64/dt/1e12:.1f} TFLOP/s")
