@@ -153,6 +153,82 @@ def test_maxpool_k3s2():
     assert rel_l2(ncdhw(xg.grad), xr.grad) < 1e-7
 
 
+@pytest.mark.parametrize("dims,train", [((2, 8, 8, 16), True), ((1, 6, 4, 6), True), ((1, 4, 8, 72), False)],
+                         ids=["rows16", "ragged_rows", "eval"])
+def test_stem_conv_bn_relu_pool_unit(dims, train):
+    """Stem unit (posenet3d_50.py:252-257) against the float64 operators: full 32-voxel row tiles of the tiled
+    BN + pool backward, a ragged tile (W = 6), and eval-mode statistics."""
+    import copy
+
+    g = torch.Generator().manual_seed(31)
+    B, D, H, W = dims
+    conv = torch.nn.Conv3d(1, 64, 7, padding=3, bias=False)
+    bn = torch.nn.BatchNorm3d(64)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+        bn.weight.copy_(1 + 0.2 * torch.randn(64, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(64, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(64, generator=g))
+        bn.running_var.copy_(1 + 0.1 * torch.rand(64, generator=g))
+    x = torch.randn(B, 1, D, H, W, generator=g)
+    convr, bnr = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    bnr.train(train)
+    xr = x.double().requires_grad_(True)
+    o = F.max_pool3d(F.relu(bnr(convr(xr))), 3, 2, 1)
+    gy = torch.randn(o.shape, generator=g)
+    (o * gy.double()).sum().backward()
+
+    convg, bng = conv.cuda(), bn.cuda()
+    bng.train(train)
+    xg = x.cuda().requires_grad_(True)
+    y = ops.stem_conv_bn_relu_pool(xg, convg, bng)
+    (y * cl(gy).cuda()).sum().backward()
+    assert rel_l2(ncdhw(y), o) < 1e-5
+    assert rel_l2(xg.grad, xr.grad) < 1e-4
+    assert rel_l2(convg.weight.grad, convr.weight.grad) < 1e-4
+    assert rel_l2(bng.weight.grad, bnr.weight.grad) < 1e-4
+    assert rel_l2(bng.bias.grad, bnr.bias.grad) < 1e-4
+
+
+@pytest.mark.parametrize("C", [64, 32], ids=["tiled_c64", "general_c32"])
+def test_stem_bn_relu_pool_abi(C):
+    """hp_stem_bn_relu_pool_forward / _backward through the C ABI: the 64-channel tiled kernels and the general
+    ones (any channel count) against float64 BatchNorm3d -> ReLU -> MaxPool3d(3,2,1) autograd."""
+    import ctypes as Ct
+
+    from hiddenpose_amd import _lib
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(77)
+    B, D, H, W = 2, 6, 4, 40
+    z = torch.randn(B, C, D, H, W, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    zr = z.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    o = F.max_pool3d(F.relu(F.batch_norm(zr, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
+    gy = torch.randn(o.shape, generator=g)
+    (o * gy.double()).sum().backward()
+    zc = cl(z).cuda()
+    mean = zc.reshape(-1, C).double().mean(0)
+    var = zc.reshape(-1, C).double().var(0, unbiased=False)
+    mean_f, rstd_f = mean.float(), (1.0 / torch.sqrt(var + 1e-5)).float()
+    gam, bet = gamma.cuda(), beta.cuda()
+    pooled = torch.empty(B, D // 2, H // 2, W // 2, C, device="cuda")
+    ws = torch.empty(int(L.hp_stem_bn_pool_workspace_bytes(C)) // 4 + 4, device="cuda")
+    st = ops._stream(zc)
+    _lib.check(L.hp_stem_bn_relu_pool_forward(zc.data_ptr(), pooled.data_ptr(), B, D, H, W, C, mean_f.data_ptr(), rstd_f.data_ptr(),
+                                              gam.data_ptr(), bet.data_ptr(), ws.data_ptr(), st), "fwd")
+    assert rel_l2(ncdhw(pooled), o) < 1e-5
+    dz, dgam, dbet = torch.empty_like(zc), torch.empty_like(gam), torch.empty_like(gam)
+    dpc = cl(gy).cuda()
+    _lib.check(L.hp_stem_bn_relu_pool_backward(zc.data_ptr(), pooled.data_ptr(), dpc.data_ptr(), dz.data_ptr(), B, D, H, W, C,
+                                               mean_f.data_ptr(), rstd_f.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1,
+                                               dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), st), "bwd")
+    assert rel_l2(ncdhw(dz), zr.grad) < 1e-4
+    assert rel_l2(dgam, gr.grad) < 1e-4
+    assert rel_l2(dbet, br.grad) < 1e-4
+
+
 def test_posenet_vs_reference_golden(golden):
     from hiddenpose_amd.posenet3d_50 import get_pose_net_50
 
