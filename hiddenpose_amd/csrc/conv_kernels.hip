@@ -538,9 +538,15 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, tap group fastest: blocks that run together share the same voxel range, so the dY rows and
   // the (shifted) X rows they gather are served by L2 / Infinity Cache instead of being re-fetched per tap
-  const int bid_tap = blockIdx.x % tap_groups;
-  const int bid_tile = (blockIdx.x / tap_groups) % tiles_total;
-  const int bid_split = blockIdx.x / (tap_groups * tiles_total);
+  // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).  The blocks that share a voxel
+  // range (same split: every tap and tile re-reads the same dY / X rows) are therefore renumbered so that XCD k
+  // owns a contiguous range of logical ids = whole splits: each per-XCD L2 then streams only its own voxel ranges
+  // instead of all of them.  Pure renumbering: any placement gives the same result.
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int bid_tap = bid % tap_groups;
+  const int bid_tile = (bid / tap_groups) % tiles_total;
+  const int bid_split = bid / (tap_groups * tiles_total);
   const int tile_n = bid_tile / tiles_c, tile_c = bid_tile % tiles_c;
   const int n0 = tile_n * TT, c0 = tile_c * TT;
   int cls = 0, tap = bid_tap * NTAP;  // (class, tap group)

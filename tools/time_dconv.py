@@ -3,7 +3,7 @@ import torch
 from hiddenpose_amd import _lib
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
-for (cin, cout, rep, dims) in [(1,1,1,(2,128,128,128)), (1,4,0,(2,128,128,128)), (4,4,0,(2,128,128,128)), (8,4,0,(2,128,128,128)), (4,8,0,(2,64,64,64)), (16,32,0,(2,16,16,16)), (64,16,0,(2,16,16,16))]:
+for (cin, cout, rep, dims) in [(1,1,1,(4,512,128,128)), (1,4,0,(4,512,128,128)), (4,4,0,(4,512,128,128)), (8,4,0,(4,512,128,128)), (4,8,0,(4,256,64,64)), (16,32,0,(4,64,16,16)), (64,16,0,(4,64,16,16))]:
     B,D,H,W = dims
     x = torch.randn(B,cin,D,H,W,device='cuda'); g = torch.randn(B,cout,D,H,W,device='cuda')
     w = torch.randn(cout,cin,3,3,3,device='cuda'); y=torch.empty_like(g); gx=torch.empty_like(x)
