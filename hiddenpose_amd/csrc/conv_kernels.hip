@@ -54,6 +54,7 @@ struct IgemmGeom {
   long M;                  // B*gd*gh*gw
   int kpt;                 // K tiles per tap (Cin/32, or padded taps/32 for the stem)
   int sw, sh, sd;          // log2 of gw, gh, gd when all three are powers of two, else -1
+  int tn;                  // > 0: 1-D grid with the N tiles of one M tile adjacent on one XCD (set by the launcher)
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -180,8 +181,20 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int cls = blockIdx.z;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // Several N tiles: block b runs on XCD b % 8, so the i-th block of an XCD takes N tile i % tn of M tile
+  // (i / tn) * 8 + xcd -- the tn blocks that gather the same A rows run back to back on one XCD and all but the
+  // first are served by its L2 (with the N tiles on grid.y they are a whole grid.x apart and re-read HBM).
+  // Measured and not adopted: classes adjacent as well (the unequal tap counts of the stride-2 data-gradient
+  // classes then unbalance the tail: 3.9 -> 6.6 ms), runs of 2-8 consecutive M tiles per XCD (no change).
+  unsigned mt_idx = blockIdx.x, nt_idx = blockIdx.y;
+  if (g.tn > 0) {
+    const unsigned i = blockIdx.x >> 3;
+    nt_idx = i % (unsigned)g.tn;
+    mt_idx = (i / (unsigned)g.tn) * 8u + (blockIdx.x & 7u);
+    if ((long)mt_idx * BM >= g.M) return;
+  }
+  const long m0 = (long)mt_idx * BM;
+  const int n0 = nt_idx * BN;
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
 
   // ---- per-thread gather rows: r0 + 32 i
@@ -1341,8 +1354,11 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const float* X, con
                             double* stats, const float* addend, hipStream_t st) {
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (g.Nout > 64) {
-    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP>), dim3(mt, (g.Nout + 127) / 128, classes), dim3(CT), 0, st, X, W,
-                       bias, Y, stats, addend, g);
+    const unsigned tn = (unsigned)((g.Nout + 127) / 128);
+    IgemmGeom gg = g;
+    gg.tn = tn > 1 ? (int)tn : 0;  // XCD-aware 1-D grid (see k_igemm)
+    const dim3 grid = tn > 1 ? dim3((mt + 7) / 8 * 8 * tn, 1, classes) : dim3(mt, 1, classes);
+    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, gg);
   } else if (g.Nout > 32) {
     hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
   } else {
