@@ -165,7 +165,7 @@ template <int BN, bool STEM, bool STATS, int NP>
 __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, float* __restrict__ Y,
                                               double* __restrict__ stats, const float* __restrict__ addend,
-                                              IgemmGeom g) {
+                                              const unsigned char* __restrict__ amask, IgemmGeom g) {
   using C = TileCfg<BN>;
   // one LDS arena: A and B tiles during the K loop, then the output staging tile of the epilogue
   constexpr bool BF = NP > 0;  // NP = 0: exact-fp32 MFMA; NP >= 1: bf16 MFMA on NP operand planes
@@ -443,7 +443,14 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           }
           if (addend) {
-            const float4 av = *(const float4*)(addend + orow * g.Nout + n);
+            float4 av = *(const float4*)(addend + orow * g.Nout + n);
+            if (amask) {  // byte per channel quad (hp_bn_apply's relu_mask): the addend is dy (.) mask, never stored
+              const unsigned mk = amask[(orow * g.Nout + n) >> 2];
+              av.x = (mk & 1u) ? av.x : 0.f;
+              av.y = (mk & 2u) ? av.y : 0.f;
+              av.z = (mk & 4u) ? av.z : 0.f;
+              av.w = (mk & 8u) ? av.w : 0.f;
+            }
             v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
           }
           *(float4*)yp = v;
@@ -1351,40 +1358,41 @@ static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
 
 template <bool STEM, bool STATS, int NP>
 static void launch_igemm_bn(const IgemmGeom& g, int classes, const float* X, const float* W, const float* bias, float* Y,
-                            double* stats, const float* addend, hipStream_t st) {
+                            double* stats, const float* addend, const unsigned char* amask, hipStream_t st) {
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (g.Nout > 64) {
     const unsigned tn = (unsigned)((g.Nout + 127) / 128);
     IgemmGeom gg = g;
     gg.tn = tn > 1 ? (int)tn : 0;  // XCD-aware 1-D grid (see k_igemm)
     const dim3 grid = tn > 1 ? dim3((mt + 7) / 8 * 8 * tn, 1, classes) : dim3(mt, 1, classes);
-    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, gg);
+    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
   } else if (g.Nout > 32) {
-    hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
+    hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
   } else {
-    hipLaunchKernelGGL((k_igemm<32, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, g);
+    hipLaunchKernelGGL((k_igemm<32, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
   }
 }
 
 template <int NP>
 static void launch_igemm_p(const IgemmGeom& g, int classes, bool stem, const float* X, const float* W, const float* bias,
-                           float* Y, double* stats, const float* addend, hipStream_t st) {
+                           float* Y, double* stats, const float* addend, const unsigned char* amask, hipStream_t st) {
   if (stem) {
-    if (stats) launch_igemm_bn<true, true, NP>(g, classes, X, W, bias, Y, stats, addend, st);
-    else launch_igemm_bn<true, false, NP>(g, classes, X, W, bias, Y, stats, addend, st);
+    if (stats) launch_igemm_bn<true, true, NP>(g, classes, X, W, bias, Y, stats, addend, amask, st);
+    else launch_igemm_bn<true, false, NP>(g, classes, X, W, bias, Y, stats, addend, amask, st);
   } else {
-    if (stats) launch_igemm_bn<false, true, NP>(g, classes, X, W, bias, Y, stats, addend, st);
-    else launch_igemm_bn<false, false, NP>(g, classes, X, W, bias, Y, stats, addend, st);
+    if (stats) launch_igemm_bn<false, true, NP>(g, classes, X, W, bias, Y, stats, addend, amask, st);
+    else launch_igemm_bn<false, false, NP>(g, classes, X, W, bias, Y, stats, addend, amask, st);
   }
 }
 
 static void launch_igemm(const IgemmGeom& g, int classes, bool stem, int planes, const float* X, const float* W,
-                         const float* bias, float* Y, double* stats, const float* addend, hipStream_t st) {
+                         const float* bias, float* Y, double* stats, const float* addend, hipStream_t st,
+                         const unsigned char* amask = nullptr) {
   switch (planes) {
-    case 1: launch_igemm_p<1>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
-    case 2: launch_igemm_p<2>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
-    case 3: launch_igemm_p<3>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
-    default: launch_igemm_p<0>(g, classes, stem, X, W, bias, Y, stats, addend, st); break;
+    case 1: launch_igemm_p<1>(g, classes, stem, X, W, bias, Y, stats, addend, amask, st); break;
+    case 2: launch_igemm_p<2>(g, classes, stem, X, W, bias, Y, stats, addend, amask, st); break;
+    case 3: launch_igemm_p<3>(g, classes, stem, X, W, bias, Y, stats, addend, amask, st); break;
+    default: launch_igemm_p<0>(g, classes, stem, X, W, bias, Y, stats, addend, amask, st); break;
   }
 }
 
@@ -1495,10 +1503,17 @@ extern "C" int hp_linear_forward(const float* x, const float* w, const float* bi
 
 extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                                        const float* addend, void* stream) {
+  return hp_conv3d_backward_data_masked(d, dy, w_dgrad, dx, addend, nullptr, stream);
+}
+
+extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                                              const float* addend, const unsigned char* addend_mask, void* stream) {
   HP_REQUIRE(d && dy && w_dgrad && dx, "hp_conv3d_backward_data: null argument");
   ConvPlan p;
   int rc = make_plan(*d, p);
   if (rc) return rc;
+  HP_REQUIRE(!addend_mask || (addend && !p.stem && !p.dgrad_zero_fill && d->Cin % 4 == 0 && d->Cin > 32),
+             "hp_conv3d_backward_data_masked: a masked addend needs a dense data gradient with > 32 input channels, a multiple of 4");
   hipStream_t st = (hipStream_t)stream;
   if (p.stem) {
     HP_REQUIRE(d->Cout == 64, "stem data gradient: 64 output channels expected (got %d)", d->Cout);
@@ -1519,7 +1534,7 @@ extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, c
   }
   {
     HP_PROF("conv_igemm_dgrad", st);
-    launch_igemm(p.dgrad, p.dgrad_classes, false, p.planes, dy, w_dgrad, nullptr, dx, nullptr, addend, st);
+    launch_igemm(p.dgrad, p.dgrad_classes, false, p.planes, dy, w_dgrad, nullptr, dx, nullptr, addend, st, addend_mask);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

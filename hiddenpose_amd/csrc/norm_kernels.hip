@@ -226,6 +226,32 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const float4* __restri
   }
 }
 
+// Pass 2 for units whose ReLU mask is the byte mask of the forward apply (units with a residual, or a shortcut unit
+// fed by such a unit's output gradient): g = dy (.) mask is rebuilt from the byte instead of being parked by pass 1,
+// so neither this unit nor the consumer of the shortcut gradient moves a masked copy of dy through memory.
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const float4* __restrict__ dy, const float4* __restrict__ z,
+                                                              float4* __restrict__ dz, long n4, int C4,
+                                                              const float4* __restrict__ ca, const float4* __restrict__ cb,
+                                                              const float4* __restrict__ cc,
+                                                              const unsigned char* __restrict__ mask) {
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    float4 gg = dy[i];
+    const unsigned mk = mask[i];
+    const float4 v = z[i], a = ca[c], b = cb[c], k = cc[c];
+    gg.x = (mk & 1u) ? gg.x : 0.f;
+    gg.y = (mk & 2u) ? gg.y : 0.f;
+    gg.z = (mk & 4u) ? gg.z : 0.f;
+    gg.w = (mk & 8u) ? gg.w : 0.f;
+    float4 o;
+    o.x = a.x * gg.x + b.x * v.x + k.x;
+    o.y = a.y * gg.y + b.y * v.y + k.y;
+    o.z = a.z * gg.z + b.z * v.z + k.z;
+    o.w = a.w * gg.w + b.w * v.w + k.w;
+    dz[i] = o;
+  }
+}
+
 // MaxPool3d(kernel 3, stride 2, pad 1), channels-last
 __global__ __launch_bounds__(ET) void k_maxpool3_fwd(const float4* __restrict__ x, float4* __restrict__ y, int B, int D,
                                                      int H, int W, int C4) {
@@ -693,7 +719,9 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   // g buffer: caller-provided g_out (residual units: g is also the gradient of the shortcut), or none at all when
   // pass 2 can rebuild the mask itself (no forward output given: mask from z, or no ReLU); dy must not alias dz then
   const bool remask = !g_out && !y && !relu_mask && dy != dz;
-  float* gbuf = remask ? nullptr : g_out ? g_out : dz;
+  // byte mask given and nobody wants g: pass 2 re-applies the byte mask to dy (nothing parked)
+  const bool bytemask = relu && relu_mask && !g_out && !y;
+  float* gbuf = (remask || bytemask) ? nullptr : g_out ? g_out : dz;
   {
     HP_PROF("bn_bwd_reduce", st);
     const int rows_per_pass = C4 < ET ? ET / C4 : 1;
@@ -707,7 +735,10 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   {
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
-    if (remask)
+    if (bytemask)
+      hipLaunchKernelGGL(k_bn_bwd_apply_bytemask, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, (const float4*)z,
+                         (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
+    else if (remask)
       hipLaunchKernelGGL(k_bn_bwd_apply_mask, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, (const float4*)z,
                          (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean,
                          (const float4*)rstd, (const float4*)gamma, (const float4*)beta_for_mask, relu);

@@ -365,14 +365,26 @@ class GradLink:
     conv1 + identity shortcut, or conv1 + shortcut convolution) from the autograd node that produces it
     first to the data-gradient GEMM that runs last, which adds it in its epilogue.  Replaces the
     separate accumulation pass autograd would issue."""
-    __slots__ = ("g", "arrivals")
+    __slots__ = ("g", "arrivals", "mask")
 
     def __init__(self):
         self.g = None
         self.arrivals = 0
+        self.mask = None   # byte mask gating `g` (identity shortcut: g is the block's raw output gradient)
 
 
-def _conv_grads(desc, x, w, dz, need_dx, addend=None):
+class ResLink:
+    """Joins the shortcut unit (downsample conv + BN) of a Bottleneck to the unit that adds its output as the
+    residual.  The gradient of the residual branch is dy (.) [block output > 0]; instead of writing that product
+    the residual unit hands back dy itself and leaves the sign mask of its output here, and the shortcut unit's
+    BatchNorm backward applies the mask while it reads dy."""
+    __slots__ = ("mask",)
+
+    def __init__(self):
+        self.mask = None
+
+
+def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
     """(dx, dw) of z = conv(x, w) given dz; all channels-last, dw in the torch weight layout."""
     L = _lib.lib()
     st = _stream(x)
@@ -380,8 +392,13 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None):
     if need_dx:
         _, wd = _pack(desc, w, False, True)
         dx = torch.empty_like(x)
-        _lib.check(L.hp_conv3d_backward_data(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend), st),
-                   "hp_conv3d_backward_data")
+        if addend_mask is not None:
+            _lib.check(L.hp_conv3d_backward_data_masked(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(),
+                                                        addend.data_ptr(), addend_mask.data_ptr(), st),
+                       "hp_conv3d_backward_data_masked")
+        else:
+            _lib.check(L.hp_conv3d_backward_data(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend), st),
+                       "hp_conv3d_backward_data")
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
     dwp = torch.empty(n, dtype=torch.float32, device=x.device)
     _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), st),
@@ -395,7 +412,7 @@ class _ConvBnAct(torch.autograd.Function):
     """y = act(BN(conv(x)) [+ res]) with the BN batch statistics reduced in the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None):
+    def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None, res_link=None):
         L = _lib.lib()
         x = x.contiguous()
         cout = w.shape[1] if transposed else w.shape[0]
@@ -432,7 +449,7 @@ class _ConvBnAct(torch.autograd.Function):
         # without a residual the mask is rebuilt from z; y itself is kept only by the consumer that reads it as input
         ctx.save_for_backward(x, w, gamma, beta, z, mask, mean, rstd)
         ctx.cfg = (desc, relu, train, res is not None)
-        ctx.links = (link_in, link_out)
+        ctx.links = (link_in, link_out, res_link)
         return y
 
     @staticmethod
@@ -444,30 +461,44 @@ class _ConvBnAct(torch.autograd.Function):
         M = z.numel() // cout
         dy = dy.contiguous()
         st = _stream(x)
+        link_in, link_out, res_link = ctx.links
         with torch.cuda.device(x.device):
             dz = torch.empty_like(z)
-            g = torch.empty_like(z) if has_res else None
+            # Residual branch gradient g = dy (.) [y > 0].  When its consumer is one of our own nodes (the block's conv1
+            # data gradient through link_out, or the shortcut unit through res_link) it takes dy and the byte mask
+            # instead, and g is never written.
+            deferred = has_res and mask is not None and (link_out is not None or res_link is not None)
+            g = torch.empty_like(z) if (has_res and not deferred) else None
+            in_mask, relu_flag = mask, relu
+            if res_link is not None and not has_res and res_link.mask is not None:
+                # shortcut unit (no ReLU of its own): the incoming dy still lacks the residual unit's output mask
+                in_mask, relu_flag, res_link.mask = res_link.mask, True, None
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(gamma)
             ws = torch.empty(int(L.hp_bn_backward_workspace_bytes(cout)) // 4 + 2, dtype=torch.float32, device=x.device)
             _lib.check(L.hp_bn_backward(dy.data_ptr(), None, z.data_ptr(), _lib.ptr(g), dz.data_ptr(), M, cout,
-                                        mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
-                                        1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(mask), ws.data_ptr(), st),
+                                        mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu_flag else 0,
+                                        1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(in_mask), ws.data_ptr(), st),
                        "hp_bn_backward")
-            link_in, link_out = ctx.links
-            addend = None
+            addend = addend_mask = None
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:
                 link_in.arrivals -= 1
                 addend, link_in.g = link_in.g, None
+                addend_mask, link_in.mask = link_in.mask, None
                 last = link_in.arrivals == 0
-            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend)
+            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask)
             if not last:           # first of two convolutions reading the block input: park the partial sum
                 link_in.g, dx = dx, None
             gres = g
-            if link_out is not None and has_res:   # identity shortcut: hand g to the block's conv1 data gradient
-                link_out.g, gres = g, None
-        return dx, dw, dgamma, dbeta, gres, None, None, None, None, None, None, None, None
+            if link_out is not None and has_res:   # identity shortcut: hand the gradient to the block's conv1 data gradient
+                if deferred:
+                    link_out.g, link_out.mask, gres = dy, mask, None
+                else:
+                    link_out.g, gres = g, None
+            elif deferred:                         # shortcut unit: it receives dy itself and masks it on the fly
+                res_link.mask, gres = mask, dy
+        return dx, dw, dgamma, dbeta, gres, None, None, None, None, None, None, None, None, None
 
 
 class _ConvBiasToNCDHW(torch.autograd.Function):
@@ -534,10 +565,10 @@ class _MaxPool3CL(torch.autograd.Function):
         return dx
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, res_link=None):
     """x channels-last (B,D,H,W,C)."""
     return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.kernel_size[0], conv.stride[0],
-                            conv.padding[0], False, relu, link_in, link_out)
+                            conv.padding[0], False, relu, link_in, link_out, res_link)
 
 
 def deconv_bn_relu(x, deconv, bn):

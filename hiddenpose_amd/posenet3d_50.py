@@ -41,8 +41,10 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             if link is not None:
                 link.arrivals = 2      # conv1 and the shortcut convolution both produce d(block input)
-            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link)
-            return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res)
+            # the shortcut unit takes the block's raw output gradient plus the output sign mask (hip_ops.ResLink)
+            rl = ops.ResLink() if torch.is_grad_enabled() else None
+            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link, res_link=rl)
+            return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res, res_link=rl)
         if link is not None:
             link.arrivals = 1          # conv1 adds the identity-shortcut gradient parked by conv3's node
         return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=x, link_out=link)

@@ -135,6 +135,12 @@ int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd,
  * same tensor (residual / shortcut branch) be summed in the epilogue instead of by a separate pass. */
 int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                             const float* addend, void* stream);
+/* Same with the addend gated by a byte mask (hp_bn_apply's relu_mask layout: one byte per channel quad of dx):
+ * dx = conv^T(dy) + addend (.) mask.  Bottleneck.forward's identity shortcut (posenet3d_50.py:90-93): the shortcut
+ * gradient is the block's output gradient times the sign mask of the block output, which therefore is never
+ * written as a tensor.  Dense (stride-1) data gradients with > 32 input channels, a multiple of 4, only. */
+int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                                   const float* addend, const unsigned char* addend_mask, void* stream);
 /* dw_packed (same layout as w_fwd) is zeroed and accumulated by the call. */
 int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float* dy, float* dw_packed, void* stream);
 
@@ -150,7 +156,10 @@ int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const
                 const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream);
 size_t hp_bn_backward_workspace_bytes(int C);
 /* g = dy * [y > 0] (stored to g_out if not NULL: gradient of the residual branch);
- * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL. */
+ * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL.
+ * With relu_mask and neither g_out nor y, g is never stored: both passes apply the byte mask to dy.  The same call
+ * (relu = 1, relu_mask = the byte mask of the unit that consumed this unit's output as its residual) serves a
+ * shortcut unit whose incoming gradient is that unit's masked output gradient. */
 /* The ReLU mask comes from relu_mask (hp_bn_apply's byte mask) if given, else from y, else -- unit without a
  * residual -- it is rebuilt from z and beta_for_mask. */
 int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
