@@ -43,7 +43,9 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
                                                  float4* __restrict__ y, long n4, int C4, const float4* __restrict__ mean,
                                                  const float4* __restrict__ rstd, const float4* __restrict__ gamma,
                                                  const float4* __restrict__ beta, int relu,
-                                                 unsigned char* __restrict__ mask_out) {
+                                                 unsigned char* __restrict__ mask_out, const float4* __restrict__ rmean,
+                                                 const float4* __restrict__ rrstd, const float4* __restrict__ rgamma,
+                                                 const float4* __restrict__ rbeta) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
     const float4 v = z[i], m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
@@ -57,7 +59,13 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
     o.z = fmaf(v.z, sc.z, sh.z);
     o.w = fmaf(v.w, sc.w, sh.w);
     if (res) {
-      const float4 q = res[i];
+      float4 q = res[i];
+      if (rmean) {  // the residual is a raw convolution output with a BatchNorm of its own still to be applied
+        const float4 m2 = rmean[c], r2 = rrstd[c], g2 = rgamma[c], b2 = rbeta[c];
+        const float4 sc2 = make_float4(r2.x * g2.x, r2.y * g2.y, r2.z * g2.z, r2.w * g2.w);
+        const float4 sh2 = make_float4(b2.x - m2.x * sc2.x, b2.y - m2.y * sc2.y, b2.z - m2.z * sc2.z, b2.w - m2.w * sc2.w);
+        q = make_float4(fmaf(q.x, sc2.x, sh2.x), fmaf(q.y, sc2.y, sh2.y), fmaf(q.z, sc2.z, sh2.z), fmaf(q.w, sc2.w, sh2.w));
+      }
       o.x += q.x;
       o.y += q.y;
       o.z += q.z;
@@ -687,12 +695,21 @@ extern "C" int hp_bn_eval_stats(const float* running_mean, const float* running_
 
 extern "C" int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream) {
+  return hp_bn_apply_res_bn(z, res, y, M, C, mean, rstd, gamma, beta, relu, relu_mask, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int hp_bn_apply_res_bn(const float* z, const float* res, float* y, long M, int C, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, int relu, unsigned char* relu_mask,
+                                  const float* res_mean, const float* res_rstd, const float* res_gamma, const float* res_beta,
+                                  void* stream) {
   HP_REQUIRE(z && y && mean && rstd && gamma && beta && M > 0 && C > 0 && C % 4 == 0, "hp_bn_apply: bad argument");
+  HP_REQUIRE(!res_mean || (res && res_rstd && res_gamma && res_beta), "hp_bn_apply_res_bn: incomplete residual BatchNorm");
   const long n4 = M * (C / 4);
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("bn_apply", st);
   hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)z, (const float4*)res, (float4*)y, n4,
-                     C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu, relu_mask);
+                     C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu, relu_mask,
+                     (const float4*)res_mean, (const float4*)res_rstd, (const float4*)res_gamma, (const float4*)res_beta);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

@@ -378,10 +378,11 @@ class ResLink:
     residual.  The gradient of the residual branch is dy (.) [block output > 0]; instead of writing that product
     the residual unit hands back dy itself and leaves the sign mask of its output here, and the shortcut unit's
     BatchNorm backward applies the mask while it reads dy."""
-    __slots__ = ("mask",)
+    __slots__ = ("mask", "affine")
 
     def __init__(self):
         self.mask = None
+        self.affine = None   # (mean, rstd, gamma, beta) of the shortcut's BatchNorm while its output is still raw
 
 
 def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
@@ -438,14 +439,30 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 _lib.check(L.hp_bn_eval_stats(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), cout, bn.eps,
                                               mean.data_ptr(), rstd.data_ptr(), st), "hp_bn_eval_stats")
+            if res_link is not None and res is None and not relu:
+                # Shortcut unit of a Bottleneck: its BatchNorm is applied by the unit that adds it as the residual
+                # (hp_bn_apply_res_bn); the raw convolution output travels instead of a normalised copy.
+                res_link.affine = (mean, rstd, gamma, beta)
+                ctx.save_for_backward(x, w, gamma, beta, z, None, mean, rstd)
+                ctx.cfg = (desc, relu, train, False)
+                ctx.links = (link_in, link_out, res_link)
+                return z
             y = torch.empty_like(z)
             if res is not None:
                 res = res.contiguous()
             # with a residual the backward needs the sign pattern of the output: a byte per channel quad, written here
             mask = (torch.empty(M * cout // 4, dtype=torch.uint8, device=x.device)
                     if (res is not None and relu and any(ctx.needs_input_grad)) else None)
-            _lib.check(L.hp_bn_apply(z.data_ptr(), _lib.ptr(res), y.data_ptr(), M, cout, mean.data_ptr(), rstd.data_ptr(),
-                                     gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, _lib.ptr(mask), st), "hp_bn_apply")
+            raff = res_link.affine if (res_link is not None and res is not None) else None
+            if raff is not None:
+                res_link.affine = None
+                _lib.check(L.hp_bn_apply_res_bn(z.data_ptr(), res.data_ptr(), y.data_ptr(), M, cout, mean.data_ptr(),
+                                                rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
+                                                _lib.ptr(mask), raff[0].data_ptr(), raff[1].data_ptr(), raff[2].data_ptr(),
+                                                raff[3].data_ptr(), st), "hp_bn_apply_res_bn")
+            else:
+                _lib.check(L.hp_bn_apply(z.data_ptr(), _lib.ptr(res), y.data_ptr(), M, cout, mean.data_ptr(), rstd.data_ptr(),
+                                         gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, _lib.ptr(mask), st), "hp_bn_apply")
         # without a residual the mask is rebuilt from z; y itself is kept only by the consumer that reads it as input
         ctx.save_for_backward(x, w, gamma, beta, z, mask, mean, rstd)
         ctx.cfg = (desc, relu, train, res is not None)

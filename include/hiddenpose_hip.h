@@ -154,6 +154,13 @@ int hp_bn_eval_stats(const float* running_mean, const float* running_var, int C,
  * residual needs of y (1 byte instead of 16 per channel quad). */
 int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
                 const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream);
+/* Same, with the residual given as the RAW output of the shortcut convolution and that shortcut's BatchNorm
+ * (res_mean .. res_beta, all C) applied on the fly: y = act(BN(z) + BN_res(res)) -- Bottleneck.forward with a
+ * `downsample` branch (posenet3d_50.py:86-93) without materialising the normalised shortcut tensor.  The result is
+ * bit-identical to hp_bn_apply on a stored BN_res(res). */
+int hp_bn_apply_res_bn(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, int relu, unsigned char* relu_mask, const float* res_mean,
+                       const float* res_rstd, const float* res_gamma, const float* res_beta, void* stream);
 size_t hp_bn_backward_workspace_bytes(int C);
 /* g = dy * [y > 0] (stored to g_out if not NULL: gradient of the residual branch);
  * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL.
