@@ -1529,7 +1529,8 @@ extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float
   }
   if (p.dgrad_zero_fill) {  // strided 1^3 convolution: only every second voxel per axis receives a contribution
     const size_t nb = sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin;
-    if (addend) HP_CHECK_HIP(hipMemcpyAsync(dx, addend, nb, hipMemcpyDeviceToDevice, st));
+    if (addend == dx) {}  // in place: the untouched voxels already hold the other contribution
+    else if (addend) HP_CHECK_HIP(hipMemcpyAsync(dx, addend, nb, hipMemcpyDeviceToDevice, st));
     else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
   }
   {

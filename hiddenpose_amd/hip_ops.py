@@ -392,7 +392,10 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
     dx = None
     if need_dx:
         _, wd = _pack(desc, w, False, True)
-        dx = torch.empty_like(x)
+        # strided 1^3 convolution: its gradient reaches every second voxel per axis only, so it is added into the
+        # addend's own buffer (no zero-filled tensor, no copy)
+        inplace = addend is not None and addend_mask is None and desc.k == 1 and desc.stride == 2 and not desc.transposed
+        dx = addend if inplace else torch.empty_like(x)
         if addend_mask is not None:
             _lib.check(L.hp_conv3d_backward_data_masked(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(),
                                                         addend.data_ptr(), addend_mask.data_ptr(), st),

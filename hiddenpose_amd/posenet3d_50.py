@@ -36,14 +36,19 @@ class Bottleneck(nn.Module):
         # The block input feeds two consumers; their gradients are summed inside the data-gradient GEMM that
         # finishes last (hip_ops.GradLink) instead of by a separate accumulation pass.
         link = ops.GradLink() if (torch.is_grad_enabled() and x.requires_grad) else None
+        res = rl = None
+        if self.downsample is not None:
+            # The shortcut unit is recorded FIRST so that its backward runs LAST: conv1's dense data gradient then
+            # writes d(block input) and the strided shortcut gradient is added to it in place at the voxels it
+            # reaches (the other order zero-fills a full-size tensor that conv1 has to read back as its addend).
+            # The unit takes the block's raw output gradient plus the output sign mask (hip_ops.ResLink).
+            rl = ops.ResLink() if torch.is_grad_enabled() else None
+            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link, res_link=rl)
         o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link)
         o = ops.conv_bn_act(o, self.conv2, self.bn2, relu=True)
         if self.downsample is not None:
             if link is not None:
                 link.arrivals = 2      # conv1 and the shortcut convolution both produce d(block input)
-            # the shortcut unit takes the block's raw output gradient plus the output sign mask (hip_ops.ResLink)
-            rl = ops.ResLink() if torch.is_grad_enabled() else None
-            res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link, res_link=rl)
             return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res, res_link=rl)
         if link is not None:
             link.arrivals = 1          # conv1 adds the identity-shortcut gradient parked by conv3's node

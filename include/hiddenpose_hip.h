@@ -132,7 +132,9 @@ int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_packed, float*
 int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd, const float* bias, float* y,
                       double* stats, void* stream);
 /* dx = conv^T(dy) [+ addend]: `addend` (same shape as dx, may be NULL) lets a second gradient contribution to the
- * same tensor (residual / shortcut branch) be summed in the epilogue instead of by a separate pass. */
+ * same tensor (residual / shortcut branch) be summed in the epilogue instead of by a separate pass.  For a strided
+ * 1^3 convolution (gradient reaches every second voxel per axis) addend may BE dx: the sum is then formed in place
+ * and no zero-filled or copied tensor is produced. */
 int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                             const float* addend, void* stream);
 /* Same with the addend gated by a byte mask (hp_bn_apply's relu_mask layout: one byte per channel quad of dx):
