@@ -48,6 +48,8 @@ SIGNATURES = {
     "hp_bn_apply": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _vp, _vp]),
     "hp_bn_apply_res_bn": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _vp, _fp, _fp, _fp, _fp, _vp]),
     "hp_bn_backward_workspace_bytes": (_sz, [_i]),
+    "hp_bn_backward_dual": (_i, [_fp, _vp, C.c_long, _i, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i,
+                                 _fp, _fp, _vp, _vp]),
     "hp_bn_backward": (_i, [_fp, _fp, _fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _vp, _vp]),
     "hp_maxpool3d_k3s2_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "hp_maxpool3d_k3s2_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),

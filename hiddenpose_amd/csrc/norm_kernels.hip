@@ -260,6 +260,93 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const float4* __re
   }
 }
 
+// ---- Two BatchNorm units that receive the same gradient g = dy (.) mask (Bottleneck with a shortcut convolution:
+// bn3 of the main branch and the shortcut's BatchNorm both feed the residual sum): one reduction and one apply pass
+// read dy and the byte mask once for both.  C4 <= ET is required (channel quads per row fit a workgroup pass).
+__global__ __launch_bounds__(ET) void k_bn_bwd_reduce_dual(const float4* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                           const float4* __restrict__ za, const float4* __restrict__ zb, long M,
+                                                           int C4, const float4* __restrict__ mean_a,
+                                                           const float4* __restrict__ rstd_a, const float4* __restrict__ mean_b,
+                                                           const float4* __restrict__ rstd_b, double* __restrict__ red_a,
+                                                           double* __restrict__ red_b) {
+  __shared__ float4 ssum[ET], sda[ET], sdb[ET];
+  const int tid = threadIdx.x;
+  const int rows_per_pass = ET / C4;
+  const int my_row = tid / C4, cq = tid % C4;
+  float4 s = make_float4(0, 0, 0, 0), da = s, db = s;
+  if (my_row < rows_per_pass) {
+    const float4 ma = mean_a[cq], ra = rstd_a[cq], mb = mean_b[cq], rb = rstd_b[cq];
+    for (long row = (long)blockIdx.x * rows_per_pass + my_row; row < M; row += (long)gridDim.x * rows_per_pass) {
+      const long i = row * C4 + cq;
+      float4 g = dy[i];
+      const unsigned mk = mask[i];
+      const float4 va = za[i], vb = zb[i];
+      g.x = (mk & 1u) ? g.x : 0.f;
+      g.y = (mk & 2u) ? g.y : 0.f;
+      g.z = (mk & 4u) ? g.z : 0.f;
+      g.w = (mk & 8u) ? g.w : 0.f;
+      s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+      da.x += g.x * (va.x - ma.x) * ra.x;
+      da.y += g.y * (va.y - ma.y) * ra.y;
+      da.z += g.z * (va.z - ma.z) * ra.z;
+      da.w += g.w * (va.w - ma.w) * ra.w;
+      db.x += g.x * (vb.x - mb.x) * rb.x;
+      db.y += g.y * (vb.y - mb.y) * rb.y;
+      db.z += g.z * (vb.z - mb.z) * rb.z;
+      db.w += g.w * (vb.w - mb.w) * rb.w;
+    }
+  }
+  ssum[tid] = s;
+  sda[tid] = da;
+  sdb[tid] = db;
+  __syncthreads();
+  if (my_row == 0) {
+    for (int rr = 1; rr < rows_per_pass; ++rr) {
+      const float4 a = ssum[rr * C4 + cq], b = sda[rr * C4 + cq], c = sdb[rr * C4 + cq];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      da.x += b.x; da.y += b.y; da.z += b.z; da.w += b.w;
+      db.x += c.x; db.y += c.y; db.z += c.z; db.w += c.w;
+    }
+    const int C = C4 * 4;
+    const float sv[4] = {s.x, s.y, s.z, s.w}, av[4] = {da.x, da.y, da.z, da.w}, bv[4] = {db.x, db.y, db.z, db.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(red_a + cq * 4 + e, (double)sv[e]);
+      atomicAdd(red_b + cq * 4 + e, (double)sv[e]);
+      atomicAdd(red_a + C + cq * 4 + e, (double)av[e]);
+      atomicAdd(red_b + C + cq * 4 + e, (double)bv[e]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply_dual(const float4* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                          const float4* __restrict__ za, const float4* __restrict__ zb,
+                                                          float4* __restrict__ dza, float4* __restrict__ dzb, long n4, int C4,
+                                                          const float4* __restrict__ caa, const float4* __restrict__ cba,
+                                                          const float4* __restrict__ cca, const float4* __restrict__ cab,
+                                                          const float4* __restrict__ cbb, const float4* __restrict__ ccb) {
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
+    const int c = (int)(i % C4);
+    float4 gg = dy[i];
+    const unsigned mk = mask[i];
+    const float4 va = za[i], vb = zb[i];
+    gg.x = (mk & 1u) ? gg.x : 0.f;
+    gg.y = (mk & 2u) ? gg.y : 0.f;
+    gg.z = (mk & 4u) ? gg.z : 0.f;
+    gg.w = (mk & 8u) ? gg.w : 0.f;
+    {
+      const float4 a = caa[c], b = cba[c], k = cca[c];
+      dza[i] = make_float4(a.x * gg.x + b.x * va.x + k.x, a.y * gg.y + b.y * va.y + k.y, a.z * gg.z + b.z * va.z + k.z,
+                           a.w * gg.w + b.w * va.w + k.w);
+    }
+    {
+      const float4 a = cab[c], b = cbb[c], k = ccb[c];
+      dzb[i] = make_float4(a.x * gg.x + b.x * vb.x + k.x, a.y * gg.y + b.y * vb.y + k.y, a.z * gg.z + b.z * vb.z + k.z,
+                           a.w * gg.w + b.w * vb.w + k.w);
+    }
+  }
+}
+
 // MaxPool3d(kernel 3, stride 2, pad 1), channels-last
 __global__ __launch_bounds__(ET) void k_maxpool3_fwd(const float4* __restrict__ x, float4* __restrict__ y, int B, int D,
                                                      int H, int W, int C4) {
@@ -762,6 +849,46 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
     else
       hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)gbuf, (const float4*)z,
                          (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_bn_backward_dual(const float* dy, const unsigned char* relu_mask, long M, int C, const float* z_a,
+                                   float* dz_a, const float* mean_a, const float* rstd_a, const float* gamma_a, int train_a,
+                                   float* dgamma_a, float* dbeta_a, const float* z_b, float* dz_b, const float* mean_b,
+                                   const float* rstd_b, const float* gamma_b, int train_b, float* dgamma_b, float* dbeta_b,
+                                   void* workspace, void* stream) {
+  HP_REQUIRE(dy && relu_mask && z_a && dz_a && mean_a && rstd_a && gamma_a && z_b && dz_b && mean_b && rstd_b && gamma_b &&
+                 workspace && M > 0 && C > 0 && C % 4 == 0 && C / 4 <= ET,
+             "hp_bn_backward_dual: bad argument (C must be a multiple of 4, at most %d)", 4 * ET);
+  hipStream_t st = (hipStream_t)stream;
+  // workspace = two single-unit workspaces back to back
+  const size_t half = (hp_bn_backward_workspace_bytes(C) + 15) / 16 * 16;
+  double* red_a = (double*)workspace;
+  double* red_b = (double*)((char*)workspace + half);
+  float *ca_a = (float*)(red_a + 2 * C), *cb_a = ca_a + C, *cc_a = cb_a + C;
+  float *ca_b = (float*)(red_b + 2 * C), *cb_b = ca_b + C, *cc_b = cb_b + C;
+  HP_CHECK_HIP(hipMemsetAsync(workspace, 0, 2 * half, st));
+  const int C4 = C / 4;
+  {
+    HP_PROF("bn_bwd_reduce", st);
+    const int rows_per_pass = ET / C4;
+    const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
+    hipLaunchKernelGGL(k_bn_bwd_reduce_dual, dim3(nb), dim3(ET), 0, st, (const float4*)dy, relu_mask, (const float4*)z_a,
+                       (const float4*)z_b, M, C4, (const float4*)mean_a, (const float4*)rstd_a, (const float4*)mean_b,
+                       (const float4*)rstd_b, red_a, red_b);
+  }
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red_a, M, C, mean_a, rstd_a, gamma_a, train_a,
+                     dgamma_a, dbeta_a, ca_a, cb_a, cc_a);
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red_b, M, C, mean_b, rstd_b, gamma_b, train_b,
+                     dgamma_b, dbeta_b, ca_b, cb_b, cc_b);
+  {
+    HP_PROF("bn_bwd_apply", st);
+    const long n4 = M * C4;
+    hipLaunchKernelGGL(k_bn_bwd_apply_dual, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, relu_mask, (const float4*)z_a,
+                       (const float4*)z_b, (float4*)dz_a, (float4*)dz_b, n4, C4, (const float4*)ca_a, (const float4*)cb_a,
+                       (const float4*)cc_a, (const float4*)ca_b, (const float4*)cb_b, (const float4*)cc_b);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

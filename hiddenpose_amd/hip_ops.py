@@ -378,11 +378,13 @@ class ResLink:
     residual.  The gradient of the residual branch is dy (.) [block output > 0]; instead of writing that product
     the residual unit hands back dy itself and leaves the sign mask of its output here, and the shortcut unit's
     BatchNorm backward applies the mask while it reads dy."""
-    __slots__ = ("mask", "affine")
+    __slots__ = ("mask", "affine", "short", "done")
 
     def __init__(self):
         self.mask = None
         self.affine = None   # (mean, rstd, gamma, beta) of the shortcut's BatchNorm while its output is still raw
+        self.short = None    # (z, mean, rstd, gamma, train) of the shortcut unit: the residual unit's backward runs
+        self.done = None     # both BatchNorm backwards in one pair of passes and leaves (dz, dgamma, dbeta) here
 
 
 def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
@@ -446,6 +448,7 @@ class _ConvBnAct(torch.autograd.Function):
                 # Shortcut unit of a Bottleneck: its BatchNorm is applied by the unit that adds it as the residual
                 # (hp_bn_apply_res_bn); the raw convolution output travels instead of a normalised copy.
                 res_link.affine = (mean, rstd, gamma, beta)
+                res_link.short = (z, mean, rstd, gamma, train)
                 ctx.save_for_backward(x, w, gamma, beta, z, None, mean, rstd)
                 ctx.cfg = (desc, relu, train, False)
                 ctx.links = (link_in, link_out, res_link)
@@ -483,7 +486,6 @@ class _ConvBnAct(torch.autograd.Function):
         st = _stream(x)
         link_in, link_out, res_link = ctx.links
         with torch.cuda.device(x.device):
-            dz = torch.empty_like(z)
             # Residual branch gradient g = dy (.) [y > 0].  When its consumer is one of our own nodes (the block's conv1
             # data gradient through link_out, or the shortcut unit through res_link) it takes dy and the byte mask
             # instead, and g is never written.
@@ -495,11 +497,28 @@ class _ConvBnAct(torch.autograd.Function):
                 in_mask, relu_flag, res_link.mask = res_link.mask, True, None
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(gamma)
-            ws = torch.empty(int(L.hp_bn_backward_workspace_bytes(cout)) // 4 + 2, dtype=torch.float32, device=x.device)
-            _lib.check(L.hp_bn_backward(dy.data_ptr(), None, z.data_ptr(), _lib.ptr(g), dz.data_ptr(), M, cout,
-                                        mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu_flag else 0,
-                                        1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(in_mask), ws.data_ptr(), st),
-                       "hp_bn_backward")
+            nws = (int(L.hp_bn_backward_workspace_bytes(cout)) + 15) // 16 * 16
+            if res_link is not None and not has_res and res_link.done is not None:
+                # shortcut unit whose BatchNorm backward was already run by the residual unit (dual pass below)
+                (dz, dgamma, dbeta), res_link.done = res_link.done, None
+            elif deferred and res_link is not None and res_link.short is not None and cout <= 1024:
+                (zb, mb, rb, gb, trb), res_link.short = res_link.short, None
+                dz = torch.empty_like(z)
+                dzb, dgb, dbb = torch.empty_like(zb), torch.empty_like(gb), torch.empty_like(gb)
+                ws = torch.empty(2 * nws // 4 + 8, dtype=torch.float32, device=x.device)
+                _lib.check(L.hp_bn_backward_dual(dy.data_ptr(), mask.data_ptr(), M, cout, z.data_ptr(), dz.data_ptr(),
+                                                 mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), 1 if train else 0,
+                                                 dgamma.data_ptr(), dbeta.data_ptr(), zb.data_ptr(), dzb.data_ptr(), mb.data_ptr(),
+                                                 rb.data_ptr(), gb.data_ptr(), 1 if trb else 0, dgb.data_ptr(), dbb.data_ptr(),
+                                                 ws.data_ptr(), st), "hp_bn_backward_dual")
+                res_link.done = (dzb, dgb, dbb)
+            else:
+                dz = torch.empty_like(z)
+                ws = torch.empty(nws // 4 + 2, dtype=torch.float32, device=x.device)
+                _lib.check(L.hp_bn_backward(dy.data_ptr(), None, z.data_ptr(), _lib.ptr(g), dz.data_ptr(), M, cout,
+                                            mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            1 if relu_flag else 0, 1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(),
+                                            _lib.ptr(in_mask), ws.data_ptr(), st), "hp_bn_backward")
             addend = addend_mask = None
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:

@@ -174,6 +174,14 @@ size_t hp_bn_backward_workspace_bytes(int C);
 int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask, int relu,
                    int train, float* dgamma, float* dbeta, const unsigned char* relu_mask, void* workspace, void* stream);
+/* Two BatchNorm units fed by the same gradient g = dy (.) relu_mask -- bn3 of the main branch (a) and the BatchNorm
+ * of the shortcut convolution (b) of a Bottleneck with `downsample` (posenet3d_50.py:86-93): one reduction and one
+ * apply pass serve both (dy and the mask are read once per pass instead of twice).  Same arithmetic per unit as
+ * hp_bn_backward; C <= 1024.  workspace: 2 * (hp_bn_backward_workspace_bytes(C) rounded up to 16) bytes. */
+int hp_bn_backward_dual(const float* dy, const unsigned char* relu_mask, long M, int C, const float* z_a, float* dz_a,
+                        const float* mean_a, const float* rstd_a, const float* gamma_a, int train_a, float* dgamma_a,
+                        float* dbeta_a, const float* z_b, float* dz_b, const float* mean_b, const float* rstd_b,
+                        const float* gamma_b, int train_b, float* dgamma_b, float* dbeta_b, void* workspace, void* stream);
 /* MaxPool3d(kernel 3, stride 2, padding 1) (posenet3d_50.py:184), channels-last. */
 int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
 int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H, int W,
