@@ -157,6 +157,7 @@ def bench_sformer(args):
     attn_flops = 8 * (B * 8 * 16 * 1024 * (24 + 1024) * 32 * 4 + B * 8 * 24 * ntok * 32 * 4)
     ms = prof.get("sformer_attention_patch", (0, 0.0))[1] + prof.get("sformer_attention_joint", (0, 0.0))[1]
     ach = attn_flops * args.steps / (ms / 1e3) / 1e12 if ms else None
+    apeak = MFMA_BF16_PEAK_TFLOPS if model.attention_precision == "bf16" else MFMA_F32_PEAK_TFLOPS
     print(json.dumps({
         "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -168,7 +169,7 @@ def bench_sformer(args):
                                "8 heads x 32, random-init weights"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},
         "roofline": {"kernel": "sformer_attention", "bound": "mfma", "achieved": round(ach, 2) if ach else None,
-                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4) if ach else None,
+                     "peak": apeak, "unit": "TFLOP/s", "frac": round(ach / apeak, 4) if ach else None,
                      "traffic": None}}), flush=True)
 
 
