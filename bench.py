@@ -435,8 +435,12 @@ def main():
                     fam = json.load(open(pmc))
                     key = name if name in fam else None
                     if key:
-                        roof["traffic"] = fam[key]
-                        roof["traffic_unit"] = "GB of HBM per step over the family's launches (PMC, profiles/round1_t512_pmc_hbm_traffic.csv)"
+                        per_step = n / args.steps
+                        roof["traffic"] = round(fam[key] / per_step, 3)
+                        roof["traffic_unit"] = ("GB of HBM per launch, mean over the family's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                                                "profiles/round1_t512_pmc_hbm_traffic.csv)")
+                        roof["traffic_gb_per_step"] = fam[key]
+                        roof["gflop_per_launch"] = round(conv[name] / 1e9 / per_step, 1)
             elif work and n:
                 bound, amount = work
                 avg_s = ms / n / 1e3

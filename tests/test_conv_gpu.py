@@ -229,8 +229,9 @@ def test_stem_bn_relu_pool_abi(C):
     assert rel_l2(dbet, br.grad) < 1e-4
 
 
-@pytest.mark.parametrize("stride,downsample", [(1, False), (1, True), (2, True)], ids=["identity", "shortcut_conv", "shortcut_s2"])
-def test_bottleneck_forward_backward(stride, downsample):
+@pytest.mark.parametrize("stride,downsample,train", [(1, False, True), (1, True, True), (2, True, True), (2, True, False), (1, False, False)],
+                         ids=["identity", "shortcut_conv", "shortcut_s2", "shortcut_s2_eval", "identity_eval"])
+def test_bottleneck_forward_backward(stride, downsample, train):
     """Bottleneck (posenet3d_50.py:59-95) in train mode against the same block built from float64 torch modules:
     output, input gradient and every parameter gradient.  Covers the shortcut-gradient plumbing (GradLink with a
     masked addend for the identity shortcut, ResLink for the shortcut convolution)."""
@@ -251,7 +252,12 @@ def test_bottleneck_forward_backward(stride, downsample):
     B, D = 2, 8
     x = torch.randn(B, cin, D, D, D, generator=g)
 
-    ref = copy.deepcopy(blk).double().train()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(1 + 0.2 * torch.rand(m.running_var.shape, generator=g))
+    ref = copy.deepcopy(blk).double().train(train)
     xr = x.double().requires_grad_(True)
     pre = torch.relu(xr * 1.0)  # a non-leaf input, as inside the network
 
@@ -265,7 +271,7 @@ def test_bottleneck_forward_backward(stride, downsample):
     gy = torch.randn(yr.shape, generator=g)
     (yr * gy.double()).sum().backward()
 
-    blk = blk.cuda().train()
+    blk = blk.cuda().train(train)
     xg = cl(x).cuda().requires_grad_(True)
     y = blk(torch.relu(xg * 1.0))
     (y * cl(gy).cuda()).sum().backward()
