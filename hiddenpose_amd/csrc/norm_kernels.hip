@@ -111,34 +111,55 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
         sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
         sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
       }
-      for (long row = (long)blockIdx.x * rows_per_pass + my_row; row < M; row += (long)gridDim.x * rows_per_pass) {
-        const long i = row * C4 + cq;
-        float4 g = dy[i];
-        const float4 v = z[i];
-        if (relu && mask) {
-          const unsigned mk = mask[i];
-          g.x = (mk & 1u) ? g.x : 0.f;
-          g.y = (mk & 2u) ? g.y : 0.f;
-          g.z = (mk & 4u) ? g.z : 0.f;
-          g.w = (mk & 8u) ? g.w : 0.f;
-        } else if (relu) {
-          float4 yy;
-          if (y) yy = y[i];
-          else yy = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-          g.x = yy.x > 0.f ? g.x : 0.f;
-          g.y = yy.y > 0.f ? g.y : 0.f;
-          g.z = yy.z > 0.f ? g.z : 0.f;
-          g.w = yy.w > 0.f ? g.w : 0.f;
+      // UNR rows per trip: all their loads are issued before the first use (the pass is a pure read stream and
+      // needs ~15 MB in flight chip-wide to run at HBM speed; one row per trip keeps ~6 MB in flight)
+      constexpr int UNR = 4;
+      const long stride = (long)gridDim.x * rows_per_pass;
+      for (long row0 = (long)blockIdx.x * rows_per_pass + my_row; row0 < M; row0 += UNR * stride) {
+        float4 gq[UNR], vq[UNR], yq[UNR];
+        unsigned mq[UNR];
+        bool okq[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const long row = row0 + u * stride;
+          okq[u] = row < M;
+          const long i = (okq[u] ? row : row0) * C4 + cq;
+          gq[u] = dy[i];
+          vq[u] = z[i];
+          mq[u] = (relu && mask) ? mask[i] : 0u;
+          yq[u] = (relu && !mask && y) ? y[i] : make_float4(0, 0, 0, 0);
         }
-        if (g_out) g_out[i] = g;
-        s.x += g.x;
-        s.y += g.y;
-        s.z += g.z;
-        s.w += g.w;
-        d.x += g.x * (v.x - m.x) * r.x;
-        d.y += g.y * (v.y - m.y) * r.y;
-        d.z += g.z * (v.z - m.z) * r.z;
-        d.w += g.w * (v.w - m.w) * r.w;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (!okq[u]) continue;
+          const long i = (row0 + u * stride) * C4 + cq;
+          float4 g = gq[u];
+          const float4 v = vq[u];
+          if (relu && mask) {
+            const unsigned mk = mq[u];
+            g.x = (mk & 1u) ? g.x : 0.f;
+            g.y = (mk & 2u) ? g.y : 0.f;
+            g.z = (mk & 4u) ? g.z : 0.f;
+            g.w = (mk & 8u) ? g.w : 0.f;
+          } else if (relu) {
+            float4 yy;
+            if (y) yy = yq[u];
+            else yy = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+            g.x = yy.x > 0.f ? g.x : 0.f;
+            g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f;
+            g.w = yy.w > 0.f ? g.w : 0.f;
+          }
+          if (g_out) g_out[i] = g;
+          s.x += g.x;
+          s.y += g.y;
+          s.z += g.z;
+          s.w += g.w;
+          d.x += g.x * (v.x - m.x) * r.x;
+          d.y += g.y * (v.y - m.y) * r.y;
+          d.z += g.z * (v.z - m.z) * r.z;
+          d.w += g.w * (v.w - m.w) * r.w;
+        }
       }
     }
     ssum[tid] = s;
