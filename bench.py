@@ -303,6 +303,9 @@ def main():
                     help="regressor convolution GEMM arithmetic; bf16 = BASELINE.json configs[2] (bf16 with fp32 LCT). "
                          "The headline metric (configs[1]) is fp32, the default.")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="opt-in: weight gradients on a second HIP stream (hip_ops.set_wgrad_async); single GPU only. "
+                         "Kernels then overlap, so per-kernel times and the roofline object describe contended launches.")
     args = ap.parse_args()
 
     if args.workload == "sformer":
@@ -345,6 +348,9 @@ def main():
     if args.batch:
         B = args.batch
     cfg = make_cfg(T, N, device=local, conv_precision=args.conv_precision)
+    if args.wgrad_stream:
+        from hiddenpose_amd import hip_ops as _ops
+        _ops.set_wgrad_async(True)
     bf16 = args.conv_precision != "fp32"
     # split modes issue 3 / 6 bf16 MFMAs per algorithmic product: the useful-FLOP ceiling shrinks accordingly
     mfma_terms = {"fp32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}[args.conv_precision]
@@ -410,7 +416,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.conv_precision if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
                                    f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
-                                   "accumulation) with fp32 LCT, U-Net, norms, losses and fp32 tensors in HBM" if bf16 else "fp32") + ", random-init weights", "global_batch": B * world,
+                                   "accumulation) with fp32 LCT, U-Net, norms, losses and fp32 tensors in HBM" if bf16 else "fp32") + ", random-init weights"
+                                   + (", weight gradients on a second stream (kernels overlap)" if args.wgrad_stream and world == 1 else ""),
+                       "global_batch": B * world,
                        "parallelism": f"dp{world}", "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
                        "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
             "loss": round(float(loss.item()), 6),

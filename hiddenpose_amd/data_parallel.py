@@ -59,6 +59,10 @@ class GradBucketReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
+        # gradients are accumulated into the bucket views on the main stream as soon as autograd gets them: the
+        # opt-in side-stream weight gradient (hip_ops.set_wgrad_async) would be read before it is written
+        from . import hip_ops
+        hip_ops.set_wgrad_async(False)
         if self._active:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))

@@ -387,6 +387,43 @@ class ResLink:
         self.done = None     # both BatchNorm backwards in one pair of passes and leaves (dz, dgamma, dbeta) here
 
 
+# Opt-in: weight gradients on a second HIP stream.  A weight gradient has no consumer before the optimizer (or the
+# gradient all-reduce), so it can run concurrently with the rest of backward: tails of one GEMM are filled by the
+# other's blocks and the memory-bound BatchNorm passes overlap matrix-core work (542 -> 532 ms/step at the headline
+# workload).  Off by default: with two kernels in flight the per-kernel durations that bench.py's roofline is built
+# from no longer measure the kernels themselves.  HP_WGRAD_STREAM=1 or set_wgrad_async(True) turns it on.
+_WGRAD_ASYNC = bool(int(__import__("os").environ.get("HP_WGRAD_STREAM", "0")))
+_side_streams = {}
+_joined_task = [-1]
+
+
+def set_wgrad_async(on: bool) -> bool:
+    global _WGRAD_ASYNC
+    prev, _WGRAD_ASYNC = _WGRAD_ASYNC, bool(on)
+    return prev
+
+
+def _wgrad_side_stream(device):
+    # only inside a backward pass: the join below is queued as an end-of-backward callback of that pass
+    if not _WGRAD_ASYNC or torch._C._current_graph_task_id() == -1:
+        return None
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device)
+    task = torch._C._current_graph_task_id()
+    if _joined_task[0] != task:
+        _joined_task[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+    return s
+
+
+def join_side_streams():
+    """The current stream of every device waits for the weight gradients queued on its side stream.  Runs by itself
+    when the backward pass that queued them ends, i.e. before `backward()` returns to the caller."""
+    for dev, s in _side_streams.items():
+        torch.cuda.current_stream(dev).wait_stream(s)
+
+
 def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
     """(dx, dw) of z = conv(x, w) given dz; all channels-last, dw in the torch weight layout."""
     L = _lib.lib()
@@ -406,11 +443,28 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
             _lib.check(L.hp_conv3d_backward_data(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend), st),
                        "hp_conv3d_backward_data")
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
-    dwp = torch.empty(n, dtype=torch.float32, device=x.device)
-    _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), st),
-               "hp_conv3d_backward_weight")
-    dw = torch.empty_like(w)
-    _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), st), "hp_conv3d_unpack_wgrad")
+    side = _wgrad_side_stream(x.device)
+    if side is None:
+        dwp = torch.empty(n, dtype=torch.float32, device=x.device)
+        _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), st),
+                   "hp_conv3d_backward_weight")
+        dw = torch.empty_like(w)
+        _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), st), "hp_conv3d_unpack_wgrad")
+        return dx, dw
+    # The weight gradient has no consumer before the optimizer: it runs on a second stream, concurrently with the
+    # rest of backward on the main one (join_side_streams() before the first reader of the gradients).
+    main = torch.cuda.current_stream(x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        sst = _stream(x)
+        dwp = torch.empty(n, dtype=torch.float32, device=x.device)
+        _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), sst),
+                   "hp_conv3d_backward_weight")
+        dw = torch.empty_like(w)
+        _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), sst), "hp_conv3d_unpack_wgrad")
+    for t in (x, dz, w):
+        t.record_stream(side)
+    dw.record_stream(main)
     return dx, dw
 
 

@@ -314,3 +314,32 @@ def test_posenet_vs_reference_golden(golden):
             gn = named[k].grad.cpu().numpy().reshape(-1)
             assert rel_l2(gn[idx], g["train_gs_" + k]) < 1e-2, k
             assert abs(np.sqrt((gn.astype(np.float64) ** 2).sum()) / float(g["train_gl2_" + k]) - 1) < 1e-2, k
+
+
+def test_weight_gradients_on_side_stream_match_serial():
+    """hip_ops.set_wgrad_async: weight gradients queued on a second stream are complete when backward() returns
+    (end-of-backward callback) and equal the serial ones up to the summation order of the split-K atomics."""
+    from hiddenpose_amd.posenet3d_50 import get_pose_net_50
+
+    net = get_pose_net_50()
+    hpt.fill_module(net, "pose_net.")
+    net = net.cuda().train()
+    x = (hpt.synthetic_meas(2, 32, 32, "uniform", seed=105) * 10.0).cuda()
+
+    def grads(async_on):
+        prev = ops.set_wgrad_async(async_on)
+        try:
+            net.zero_grad(set_to_none=True)
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm3d):
+                    m.reset_running_stats()
+            y = net(x)
+            (y * y).mean().backward()
+            return {k: p.grad.clone() for k, p in net.named_parameters()}
+        finally:
+            ops.set_wgrad_async(prev)
+
+    ref = grads(False)
+    got = grads(True)
+    for k in ref:
+        assert rel_l2(got[k], ref[k]) < 1e-4, k
