@@ -502,7 +502,7 @@ class _ConvBnAct(torch.autograd.Function):
                 # Shortcut unit of a Bottleneck: its BatchNorm is applied by the unit that adds it as the residual
                 # (hp_bn_apply_res_bn); the raw convolution output travels instead of a normalised copy.
                 res_link.affine = (mean, rstd, gamma, beta)
-                res_link.short = (z, mean, rstd, gamma, train)
+                res_link.short = (z.detach(), mean, rstd, gamma, train)   # an alias, not the output object: no ctx cycle
                 ctx.save_for_backward(x, w, gamma, beta, z, None, mean, rstd)
                 ctx.cfg = (desc, relu, train, False)
                 ctx.links = (link_in, link_out, res_link)
