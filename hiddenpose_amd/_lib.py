@@ -144,8 +144,9 @@ def current_stream_handle(device=None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def profile_enable(on: bool) -> None:
-    lib().hp_profile_enable(1 if on else 0)
+def profile_enable(on) -> None:
+    """True / 1: every kernel family; 2: the matrix-core convolution families only; False / 0: off."""
+    lib().hp_profile_enable(2 if on == 2 else 1 if on else 0)
 
 
 def profile_reset() -> None:

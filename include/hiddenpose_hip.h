@@ -43,6 +43,8 @@ const char* hp_last_error_string(void);
 /* Per-kernel timing with HIP events recorded on the launch stream (off by default).
  * hp_profile_get(i, ...) synchronises the recorded events and returns the launch count
  * and total milliseconds of the i-th kernel name seen since hp_profile_reset(). */
+/* on = 1: every kernel family; on = 2: only the matrix-core convolution families (names "conv_*" except the weight
+ * packing), which keeps the event overhead out of a timed region; 0: off. */
 int hp_profile_enable(int on);
 int hp_profile_reset(void);
 int hp_profile_count(void);
