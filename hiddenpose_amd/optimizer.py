@@ -5,7 +5,10 @@ from torch import optim
 
 def get_optimizer(cfg, model):
     if cfg.TRAIN.OPTIMIZER == "adam":
-        return optim.Adam(model.parameters(), lr=cfg.TRAIN.LR)
+        params = list(model.parameters())
+        # same update rule and state_dict layout; on the GPU the single fused kernel replaces ~50 multi-tensor launches
+        fused = bool(params) and all(p.is_cuda for p in params) and __import__("os").environ.get("HP_ADAM_FUSED", "1") != "0"
+        return optim.Adam(params, lr=cfg.TRAIN.LR, fused=fused)
     if cfg.TRAIN.OPTIMIZER == "sgd":
         return optim.SGD(model.parameters(), lr=cfg.TRAIN.LR, momentum=getattr(cfg.TRAIN, "MOMENTUM", 0.9),
                          weight_decay=getattr(cfg.TRAIN, "WD", 0.0), nesterov=getattr(cfg.TRAIN, "NESTEROV", False))
