@@ -15,8 +15,9 @@ constexpr int ET = 256;
 // stats[0:C] = sum, stats[C:2C] = sum of squares (fp64) over M rows
 __global__ void k_bn_finalize(const double* __restrict__ stats, long M, int C, float eps, float momentum,
                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                              float* __restrict__ running_var) {
+                              float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // BatchNorm3d's counter, in the same launch
   if (c >= C) return;
   const double m = stats[c] / (double)M;
   double var = stats[C + c] / (double)M - m * m;
@@ -785,9 +786,15 @@ using namespace hp;
 
 extern "C" int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float momentum, float* mean,
                                     float* rstd, float* running_mean, float* running_var, void* stream) {
+  return hp_bn_train_finalize_counted(stats, M, C, eps, momentum, mean, rstd, running_mean, running_var, nullptr, stream);
+}
+
+extern "C" int hp_bn_train_finalize_counted(const double* stats, long M, int C, float eps, float momentum, float* mean,
+                                            float* rstd, float* running_mean, float* running_var,
+                                            long long* num_batches_tracked, void* stream) {
   HP_REQUIRE(stats && mean && rstd && M > 0 && C > 0, "hp_bn_train_finalize: bad argument");
   hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, M, C, eps, momentum,
-                     mean, rstd, running_mean, running_var);
+                     mean, rstd, running_mean, running_var, num_batches_tracked);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

@@ -350,9 +350,22 @@ def _out_dims(desc):
     return f(desc.Di), f(desc.Hi), f(desc.Wi)
 
 
+def _same_as_packed(desc):
+    """1^3 convolutions: the packed forward / weight-gradient layout [tap][Cout][Cin] IS the torch layout
+    (Cout, Cin, 1, 1, 1), so neither a pack nor an unpack launch is needed."""
+    return desc.k == 1 and not desc.transposed
+
+
 def _pack(desc, w, want_fwd, want_dgrad):
     L = _lib.lib()
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
+    if want_fwd and _same_as_packed(desc) and w.is_contiguous():
+        wf, want_fwd = w.detach().reshape(-1), False
+        if not want_dgrad:
+            return wf, None
+        wd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        _lib.check(L.hp_conv3d_pack_weight(_C.byref(desc), w.data_ptr(), None, wd.data_ptr(), _stream(w)), "hp_conv3d_pack_weight")
+        return wf, wd
     wf = torch.empty(n, dtype=torch.float32, device=w.device) if want_fwd else None
     wd = torch.empty(w.numel(), dtype=torch.float32, device=w.device) if want_dgrad else None
     _lib.check(L.hp_conv3d_pack_weight(_C.byref(desc), w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), _stream(w)),
@@ -448,6 +461,8 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
         dwp = torch.empty(n, dtype=torch.float32, device=x.device)
         _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), st),
                    "hp_conv3d_backward_weight")
+        if _same_as_packed(desc):
+            return dx, dwp.view_as(w)
         dw = torch.empty_like(w)
         _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), st), "hp_conv3d_unpack_wgrad")
         return dx, dw
@@ -460,8 +475,11 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
         dwp = torch.empty(n, dtype=torch.float32, device=x.device)
         _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), sst),
                    "hp_conv3d_backward_weight")
-        dw = torch.empty_like(w)
-        _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), sst), "hp_conv3d_unpack_wgrad")
+        if _same_as_packed(desc):
+            dw = dwp.view_as(w)
+        else:
+            dw = torch.empty_like(w)
+            _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), sst), "hp_conv3d_unpack_wgrad")
     for t in (x, dz, w):
         t.record_stream(side)
     dw.record_stream(main)
@@ -491,10 +509,9 @@ class _ConvBnAct(torch.autograd.Function):
             rstd = torch.empty_like(mean)
             if train:
                 mom = 0.1 if bn.momentum is None else bn.momentum
-                _lib.check(L.hp_bn_train_finalize(stats.data_ptr(), M, cout, bn.eps, mom, mean.data_ptr(), rstd.data_ptr(),
-                                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), st),
-                           "hp_bn_train_finalize")
-                bn.num_batches_tracked += 1
+                _lib.check(L.hp_bn_train_finalize_counted(stats.data_ptr(), M, cout, bn.eps, mom, mean.data_ptr(), rstd.data_ptr(),
+                                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                          bn.num_batches_tracked.data_ptr(), st), "hp_bn_train_finalize")
             else:
                 _lib.check(L.hp_bn_eval_stats(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), cout, bn.eps,
                                               mean.data_ptr(), rstd.data_ptr(), st), "hp_bn_eval_stats")
@@ -692,9 +709,9 @@ class _StemConvBnReluPool(torch.autograd.Function):
             rstd = torch.empty_like(mean)
             if train:
                 mom = 0.1 if bn.momentum is None else bn.momentum
-                _lib.check(L.hp_bn_train_finalize(stats.data_ptr(), M, cout, bn.eps, mom, mean.data_ptr(), rstd.data_ptr(),
-                                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), st), "hp_bn_train_finalize")
-                bn.num_batches_tracked += 1
+                _lib.check(L.hp_bn_train_finalize_counted(stats.data_ptr(), M, cout, bn.eps, mom, mean.data_ptr(), rstd.data_ptr(),
+                                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                          bn.num_batches_tracked.data_ptr(), st), "hp_bn_train_finalize")
             else:
                 _lib.check(L.hp_bn_eval_stats(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), cout, bn.eps,
                                               mean.data_ptr(), rstd.data_ptr(), st), "hp_bn_eval_stats")

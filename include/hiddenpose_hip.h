@@ -151,6 +151,9 @@ int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float
 /* BatchNorm3d (posenet3d_50.py:70-95,133,182) on [M][C] channels-last matrices. */
 int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float momentum, float* mean, float* rstd,
                          float* running_mean, float* running_var, void* stream);
+/* Same, and BatchNorm3d's `num_batches_tracked` (int64, device) is incremented by the same launch (may be NULL). */
+int hp_bn_train_finalize_counted(const double* stats, long M, int C, float eps, float momentum, float* mean, float* rstd,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked, void* stream);
 int hp_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
                      void* stream);
 /* y = act((z - mean) * rstd * gamma + beta [+ res]);  res may be NULL; relu = 0|1.
