@@ -265,6 +265,7 @@ __global__ __launch_bounds__(UT) void k_maxpool2_bwd(const float* __restrict__ x
   }
 }
 
+constexpr int UPS_TAB = 2048;  // D + H + W of the INPUT must fit the per-axis tables of the two kernels below
 // ---- trilinear x2, align_corners=True.  src = o * (n-1)/(2n-1).
 // Forward writes into channel slice [c_off, c_off + C) of a (B, Ctot, 2D, 2H, 2W) buffer.
 __device__ __forceinline__ void lerp_src(int o, int n, int& i0, int& i1, float& w1) {
@@ -276,23 +277,39 @@ __device__ __forceinline__ void lerp_src(int o, int n, int& i0, int& i1, float& 
 }
 
 __global__ __launch_bounds__(UT) void k_upsample2_fwd(const float* __restrict__ x, float* __restrict__ y, int B, int C, int D,
-                                                      int H, int W, int Ctot, int c_off) {
+                                                      int H, int W, int Ctot, int c_off, int sw, int sh, int sd) {
+  // interpolation sources per output position of each axis (lerp_src, unchanged), built once per workgroup
+  __shared__ int f_i0[2 * UPS_TAB], f_i1[2 * UPS_TAB];
+  __shared__ float f_w[2 * UPS_TAB];
   const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  for (int e = threadIdx.x; e < Do + Ho + Wo; e += UT) {
+    const int n = e < Do ? D : e < Do + Ho ? H : W;
+    const int o = e < Do ? e : e < Do + Ho ? e - Do : e - Do - Ho;
+    lerp_src(o, n, f_i0[e], f_i1[e], f_w[e]);
+  }
+  __syncthreads();
   const long total = (long)B * C * Do * Ho * Wo;
   for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
-    const int ow = (int)(i % Wo);
-    long t = i / Wo;
-    const int oh = (int)(t % Ho);
-    t /= Ho;
-    const int od = (int)(t % Do);
-    t /= Do;
-    const int c = (int)(t % C);
-    const int b = (int)(t / C);
-    int d0, d1, h0, h1, w0, w1;
-    float fd, fh, fw;
-    lerp_src(od, D, d0, d1, fd);
-    lerp_src(oh, H, h0, h1, fh);
-    lerp_src(ow, W, w0, w1, fw);
+    int ow, oh, od, c, b;
+    if (sw >= 0) {  // power-of-two extents: shifts (five 64-bit divisions cost ~200 instructions per element)
+      ow = (int)(i & (Wo - 1));
+      oh = (int)((i >> sw) & (Ho - 1));
+      od = (int)((i >> (sw + sh)) & (Do - 1));
+      const unsigned bc = (unsigned)(i >> (sw + sh + sd));
+      c = (int)(bc % (unsigned)C);
+      b = (int)(bc / (unsigned)C);
+    } else {
+      ow = (int)(i % Wo);
+      long t = i / Wo;
+      oh = (int)(t % Ho);
+      t /= Ho;
+      od = (int)(t % Do);
+      t /= Do;
+      c = (int)(t % C);
+      b = (int)(t / C);
+    }
+    const int d0 = f_i0[od], d1 = f_i1[od], h0 = f_i0[Do + oh], h1 = f_i1[Do + oh], w0 = f_i0[Do + Ho + ow], w1 = f_i1[Do + Ho + ow];
+    const float fd = f_w[od], fh = f_w[Do + oh], fw = f_w[Do + Ho + ow];
     const float* p = x + ((long)b * C + c) * D * H * W;
     auto at = [&](int a, int bb, int cc) { return p[((long)a * H + bb) * W + cc]; };
     const float v00 = at(d0, h0, w0) * (1.f - fw) + at(d0, h0, w1) * fw;
@@ -319,49 +336,83 @@ __device__ __forceinline__ int adj_range(int i, int n, int& lo) {
   return b - a + 1;
 }
 
+// Per-axis adjoint tables in LDS: for input position p the outputs lo .. lo + cnt - 1 read it with weights wt[0 .. cnt)
+// (cnt <= 5).  They depend on the axis length only, so a workgroup builds them once (D + H + W entries) instead of
+// re-deriving up to 15 interpolation sources per voxel; the arithmetic of every weight is lerp_src's, unchanged.
+
 __global__ __launch_bounds__(UT) void k_upsample2_bwd(const float* __restrict__ dy, float* __restrict__ dx, int B, int C,
-                                                      int D, int H, int W, int Ctot, int c_off) {
+                                                      int D, int H, int W, int Ctot, int c_off, int sw, int sh, int sd) {
+  __shared__ int t_lo[UPS_TAB], t_cnt[UPS_TAB];
+  __shared__ float t_wt[UPS_TAB * 5];
   const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
-  const long total = (long)B * C * D * H * W;
-  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
-    const int w = (int)(i % W);
-    long t = i / W;
-    const int h = (int)(t % H);
-    t /= H;
-    const int d = (int)(t % D);
-    t /= D;
-    const int c = (int)(t % C);
-    const int b = (int)(t / C);
-    // per axis: the outputs that read this input voxel and their interpolation weights (at most 5; weights are
-    // separable, so the per-axis lists are built once instead of inside the triple loop)
-    int od[8], oh[8], ow[8], nd = 0, nh = 0, nw = 0;
-    float wd[8], wh[8], ww[8];
-    auto axis = [&](int pos, int n, int* idx, float* wt, int& cnt) {
-      int lo;
-      const int m = adj_range(pos, n, lo);
-      for (int a = 0; a < m; ++a) {
-        int i0, i1;
-        float f;
-        lerp_src(lo + a, n, i0, i1, f);
-        const float wgt = (i0 == pos ? 1.f - f : 0.f) + (i1 == pos ? f : 0.f);
-        if (wgt != 0.f && cnt < 8) {
-          idx[cnt] = lo + a;
-          wt[cnt] = wgt;
-          ++cnt;
+  for (int e = threadIdx.x; e < D + H + W; e += UT) {
+    const int n = e < D ? D : e < D + H ? H : W;
+    const int pos = e < D ? e : e < D + H ? e - D : e - D - H;
+    int lo;
+    const int m = adj_range(pos, n, lo);
+    int first = -1, cnt = 0;
+    float wts[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < m; ++a) {
+      int i0, i1;
+      float f;
+      lerp_src(lo + a, n, i0, i1, f);
+      const float wgt = (i0 == pos ? 1.f - f : 0.f) + (i1 == pos ? f : 0.f);
+      if (wgt != 0.f) {
+        if (first < 0) first = lo + a;
+        const int k = lo + a - first;  // outputs with a non-zero weight are consecutive; zero weights in between stay 0
+        if (k < 5) {
+          wts[k] = wgt;
+          cnt = k + 1;
         }
       }
-    };
-    axis(d, D, od, wd, nd);
-    axis(h, H, oh, wh, nh);
-    axis(w, W, ow, ww, nw);
+    }
+    t_lo[e] = first < 0 ? 0 : first;
+    t_cnt[e] = cnt;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t_wt[e * 5 + k] = wts[k];
+  }
+  __syncthreads();
+  const long total = (long)B * C * D * H * W;
+  for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
+    int w, h, d, c, b;
+    if (sw >= 0) {
+      w = (int)(i & (W - 1));
+      h = (int)((i >> sw) & (H - 1));
+      d = (int)((i >> (sw + sh)) & (D - 1));
+      const unsigned bc = (unsigned)(i >> (sw + sh + sd));
+      c = (int)(bc % (unsigned)C);
+      b = (int)(bc / (unsigned)C);
+    } else {
+      w = (int)(i % W);
+      long t = i / W;
+      h = (int)(t % H);
+      t /= H;
+      d = (int)(t % D);
+      t /= D;
+      c = (int)(t % C);
+      b = (int)(t / C);
+    }
+    const int ed = d, eh = D + h, ew = D + H + w;
+    const int od0 = t_lo[ed], nd = t_cnt[ed], oh0 = t_lo[eh], nh = t_cnt[eh], ow0 = t_lo[ew], nw = t_cnt[ew];
+    float ww[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ww[k] = t_wt[ew * 5 + k];
     const float* p = dy + ((long)b * Ctot + c_off + c) * Do * Ho * Wo;
     float acc = 0.f;
-    for (int a = 0; a < nd; ++a)
+    for (int a = 0; a < nd; ++a) {
+      const float wa = t_wt[ed * 5 + a];
       for (int bb = 0; bb < nh; ++bb) {
-        const float wab = wd[a] * wh[bb];
-        const float* row = p + ((long)od[a] * Ho + oh[bb]) * Wo;
-        for (int cc = 0; cc < nw; ++cc) acc += wab * ww[cc] * row[ow[cc]];
+        const float wab = wa * t_wt[eh * 5 + bb];
+        const float* row = p + ((long)(od0 + a) * Ho + (oh0 + bb)) * Wo;
+        // the <= 5 samples of a row are read unconditionally (clamped) and weighted 0 beyond nw
+        float r[5];
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) r[cc] = row[min(ow0 + cc, Wo - 1)];
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc)
+          if (cc < nw) acc += wab * ww[cc] * r[cc];
       }
+    }
     dx[i] = acc;
   }
 }
@@ -445,6 +496,16 @@ __global__ __launch_bounds__(UT) void k_conv1_bwd(const float* __restrict__ x, c
   }
 }
 
+// log2 of the three extents when all are powers of two, else -1 each
+static void pow2_shifts(int d, int h, int w, int& sd, int& sh, int& sw) {
+  auto lg = [](int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+  };
+  sd = lg(d), sh = lg(h), sw = lg(w);
+  if (sd < 0 || sh < 0 || sw < 0) sd = sh = sw = -1;
+}
 static unsigned ugrid(long n) { return (unsigned)std::max<long>(1, std::min<long>((n + UT - 1) / UT, 256 * 8)); }
 static unsigned chunks_for(long V, long planes) {
   // enough blocks to fill the chip without shredding small planes
@@ -532,9 +593,13 @@ extern "C" int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* 
 extern "C" int hp_upsample_trilinear2x_forward(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot,
                                                int c_off, void* stream) {
   HP_REQUIRE(x && y && c_off >= 0 && c_off + C <= Ctot, "hp_upsample_trilinear2x_forward: bad argument");
+  HP_REQUIRE(D + H + W <= UPS_TAB, "hp_upsample_trilinear2x_forward: D + H + W must not exceed %d", UPS_TAB);
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("upsample2_fwd", st);
-  hipLaunchKernelGGL(k_upsample2_fwd, dim3(ugrid((long)B * C * D * H * W * 8)), dim3(UT), 0, st, x, y, B, C, D, H, W, Ctot, c_off);
+  int sw, sh, sd;
+  pow2_shifts(2 * D, 2 * H, 2 * W, sd, sh, sw);
+  hipLaunchKernelGGL(k_upsample2_fwd, dim3(ugrid((long)B * C * D * H * W * 8)), dim3(UT), 0, st, x, y, B, C, D, H, W, Ctot, c_off, sw,
+                     sh, sd);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
@@ -542,9 +607,13 @@ extern "C" int hp_upsample_trilinear2x_forward(const float* x, float* y, int B, 
 extern "C" int hp_upsample_trilinear2x_backward(const float* dy, float* dx, int B, int C, int D, int H, int W, int Ctot,
                                                 int c_off, void* stream) {
   HP_REQUIRE(dy && dx && c_off >= 0 && c_off + C <= Ctot, "hp_upsample_trilinear2x_backward: bad argument");
+  HP_REQUIRE(D + H + W <= UPS_TAB, "hp_upsample_trilinear2x_backward: D + H + W must not exceed %d", UPS_TAB);
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("upsample2_bwd", st);
-  hipLaunchKernelGGL(k_upsample2_bwd, dim3(ugrid((long)B * C * D * H * W)), dim3(UT), 0, st, dy, dx, B, C, D, H, W, Ctot, c_off);
+  int sw, sh, sd;
+  pow2_shifts(D, H, W, sd, sh, sw);
+  hipLaunchKernelGGL(k_upsample2_bwd, dim3(ugrid((long)B * C * D * H * W)), dim3(UT), 0, st, dy, dx, B, C, D, H, W, Ctot, c_off, sw, sh,
+                     sd);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
