@@ -761,6 +761,98 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
   }
 }
 
+// ---------------------------------------------------------------- weight gradient of a dense 1^3 convolution, thin side
+// dW[n][c] = sum_m dY[m][n] * X[m][c] when one side has 64 channels and the other 256 (layer-1 Bottlenecks): the
+// square 64 x 64 tile of k_wgrad leaves every wave a single MFMA tile (2 fragment reads per MFMA, ~80 TFLOP/s, and
+// the 64-channel operand re-read by four blocks).  Here ONE block holds the whole TN x TC = 256 x 64 (or 64 x 256)
+// gradient, every wave a 64 x 64 part of it (2 x 2 MFMA tiles, 1 fragment read per MFMA), and both operands stream
+// through exactly once; the voxel range is split over blocks (XCD-aware numbering as in k_wgrad), partial sums meet
+// in fp32 atomics.  No taps, no coordinate decode: row m of X and row m of dY belong together.
+template <int TN, int TC>
+__global__ __launch_bounds__(CT) void k_wgrad_dense(const float* __restrict__ X, const float* __restrict__ dY,
+                                                    float* __restrict__ dW, long M, int Nout, int Cin, int msplit,
+                                                    int tiles_c) {
+  constexpr int QY = TN / 4, QX = TC / 4;            // float4 per staged row
+  constexpr int PY = CT / QY, PX = CT / QX;          // rows per staging pass
+  constexpr int RY = WG_KM / PY, RX = WG_KM / PX;    // rows per thread and step
+  constexpr int WN_ = TN >= TC ? 4 : 1, WC_ = 4 / WN_;  // wave grid: every wave owns 64 x 64
+  static_assert(TN / WN_ == 64 && TC / WC_ == 64, "64 x 64 per wave");
+  __shared__ __attribute__((aligned(16))) float Ys[WG_KM * TN];
+  __shared__ __attribute__((aligned(16))) float Xs[WG_KM * TC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int tiles_total = gridDim.x / msplit;
+  const int bid_tile = bid % tiles_total, bid_split = bid / tiles_total;
+  const int n0 = (bid_tile / tiles_c) * TN, c0 = (bid_tile % tiles_c) * TC;
+  const long chunk = ((M + msplit - 1) / msplit + WG_KM - 1) / WG_KM * WG_KM;
+  const long mbeg = (long)bid_split * chunk, mend = mbeg + chunk < M ? mbeg + chunk : M;
+  const int yq = tid % QY, yr = tid / QY, xq = tid % QX, xr = tid / QX;
+  const int wn = wave / WC_, wc = wave % WC_;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 vy[RY], vx[RX];
+  auto load_step = [&](long mb) {
+#pragma unroll
+    for (int h = 0; h < RY; ++h) {
+      const long m = mb + yr + PY * h;
+      vy[h] = m < mend ? *(const float4*)(dY + m * Nout + n0 + yq * 4) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < RX; ++h) {
+      const long m = mb + xr + PX * h;
+      vx[h] = m < mend ? *(const float4*)(X + m * Cin + c0 + xq * 4) : make_float4(0, 0, 0, 0);
+    }
+  };
+  if (mbeg < mend) load_step(mbeg);
+  for (long mb = mbeg; mb < mend; mb += WG_KM) {
+    __syncthreads();  // fragment reads of the previous step are done
+#pragma unroll
+    for (int h = 0; h < RY; ++h) *(float4*)(Ys + (yr + PY * h) * TN + yq * 4) = vy[h];
+#pragma unroll
+    for (int h = 0; h < RX; ++h) *(float4*)(Xs + (xr + PX * h) * TC + xq * 4) = vx[h];
+    __syncthreads();
+    if (mb + WG_KM < mend) load_step(mb + WG_KM);
+    float fa[2][2], fb[2][2];
+    auto frag = [&](int set, int kk) {
+      const int mrow = 2 * kk + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[set][i] = Ys[mrow * TN + wn * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[set][j] = Xs[mrow * TC + wc * 64 + j * 32 + (lane & 31)];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < WG_KM / 2; ++kk) {
+      const int cur = kk & 1;
+      if (kk + 1 < WG_KM / 2) frag(cur ^ 1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+        atomicAdd(dW + (long)n * Cin + c, acc[i][j][r]);
+      }
+}
+
 // ---------------------------------------------------------------- stem data gradient
 // dX[j + k - 3] += sum_n dZ[j][n] * w[n][k]   (7^3 taps, 64 channels -> 1 channel)
 // As an implicit GEMM this has N = 1, so it is computed the other way round: per 4x4x8 voxel
@@ -1560,6 +1652,25 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
                        d->Hi, d->Wi, pz, py, px, tiles, per_wg, Kc);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
+  }
+  // dense 1^3 convolution with a 64-channel side and a 256-multiple side: one block per voxel split holds TN x TC
+  if (!p.stem && p.planes == 0 && g.mode == MODE_CONV && g.k == 1 && g.s == 1 && g.os == 1 && g.M >= (1l << 16)) {
+    const bool wide_n = g.Nout % 256 == 0 && g.Cin == 64, wide_c = g.Nout == 64 && g.Cin % 256 == 0;
+    if (wide_n || wide_c) {
+      const int tiles = wide_n ? g.Nout / 256 : g.Cin / 256;
+      // ~1024 blocks = one resident wave of 4 per CU (768 / 2048 / 4096 measured 16 % / 2 % / 5 % slower)
+      long ms = std::max<long>(1, std::min<long>(1024 / tiles, g.M / (4 * WG_KM)));
+      ms = std::max<long>(8, ms / 8 * 8);  // a multiple of 8 keeps the XCD renumbering on
+      HP_PROF("conv_wgrad", st);
+      if (wide_n)
+        hipLaunchKernelGGL((k_wgrad_dense<256, 64>), dim3((unsigned)(tiles * ms)), dim3(CT), 0, st, x, dy, dw_packed, g.M, g.Nout,
+                           g.Cin, (int)ms, 1);
+      else
+        hipLaunchKernelGGL((k_wgrad_dense<64, 256>), dim3((unsigned)(tiles * ms)), dim3(CT), 0, st, x, dy, dw_packed, g.M, g.Nout,
+                           g.Cin, (int)ms, tiles);
+      HP_CHECK_HIP(hipGetLastError());
+      return HP_OK;
+    }
   }
   const int TT = (g.Nout >= 128 && Kc >= 128) ? 128 : 64;
   // 64-wide tiles of a plain 3^3 convolution: 4 taps per block share the staged dY tile

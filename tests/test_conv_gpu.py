@@ -34,6 +34,9 @@ CASES = [
     # long and wide: >= 131072 voxels, 256 output channels (forward; data gradient)
     ("big_fwd256", 32, 256, 1, 1, 0, False, (1, 32, 64, 64)),
     ("big_dgrad256", 256, 32, 1, 1, 0, False, (1, 33, 64, 64)),
+    # >= 65536 voxels, 64 channels on one side and 256 on the other: the one-block-per-split weight gradient
+    ("k1_thin_n", 64, 256, 1, 1, 0, False, (1, 16, 64, 65)),
+    ("k1_thin_c", 256, 64, 1, 1, 0, False, (1, 16, 64, 65)),
 ]
 
 
