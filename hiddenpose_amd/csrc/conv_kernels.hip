@@ -128,7 +128,18 @@ __host__ __device__ inline int class_ntaps(const IgemmGeom& g, int cls) {
 __device__ __forceinline__ void tap_info(const IgemmGeom& g, int cls, int t, int& dz, int& dy, int& dx, int& widx) {
   if (g.mode == MODE_CONV) {
     const int kk = g.k;
-    const int a = t / (kk * kk), b = (t / kk) % kk, c = t % kk;
+    // literal divisors for the kernel sizes in use: a runtime integer division is ~40 scalar instructions, and this
+    // runs once per tap inside the K loop (every second K tile of a 64-channel 3^3 layer)
+    int a, b, c;
+    if (kk == 3) {
+      a = t / 9, b = (t / 3) % 3, c = t % 3;
+    } else if (kk == 4) {
+      a = t >> 4, b = (t >> 2) & 3, c = t & 3;
+    } else if (kk == 1) {
+      a = b = c = 0;
+    } else {
+      a = t / (kk * kk), b = (t / kk) % kk, c = t % kk;
+    }
     dz = g.flip ? g.p - a : a - g.p;
     dy = g.flip ? g.p - b : b - g.p;
     dx = g.flip ? g.p - c : c - g.p;
