@@ -446,50 +446,6 @@ __global__ __launch_bounds__(ET) void k_maxpool3_bwd(const float4* __restrict__ 
   }
 }
 
-// ---- stem: BatchNorm + ReLU + MaxPool3d(3,2,1) without materialising the normalised 64-channel volume.
-// y = relu(z * sc + sh) with sc = rstd * gamma, sh = beta - mean * sc  (recomputed wherever it is needed)
-__device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
-  return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
-                     fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
-}
-
-__global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restrict__ z, float4* __restrict__ p, int B, int D,
-                                                          int H, int W, int C4, const float4* __restrict__ sc,
-                                                          const float4* __restrict__ sh) {
-  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
-  const long total = (long)B * Do * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    long t = i / C4;
-    const int ow = (int)(t % Wo);
-    t /= Wo;
-    const int oh = (int)(t % Ho);
-    t /= Ho;
-    const int od = (int)(t % Do);
-    const int b = (int)(t / Do);
-    const float4 a = sc[c], s0 = sh[c];
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // ReLU output is >= 0 and every window holds a valid voxel
-    for (int dz = -1; dz <= 1; ++dz) {
-      const int zz = 2 * od + dz;
-      if ((unsigned)zz >= (unsigned)D) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = 2 * oh + dy;
-        if ((unsigned)yy >= (unsigned)H) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int xx = 2 * ow + dx;
-          if ((unsigned)xx >= (unsigned)W) continue;
-          const float4 v = bn_relu4(z[((((long)b * D + zz) * H + yy) * W + xx) * C4 + c], a, s0);
-          m.x = fmaxf(m.x, v.x);
-          m.y = fmaxf(m.y, v.y);
-          m.z = fmaxf(m.z, v.z);
-          m.w = fmaxf(m.w, v.w);
-        }
-      }
-    }
-    p[i] = m;
-  }
-}
-
 // voxel index -> (b, d, h, w); shifts when all three extents are powers of two (runtime integer division costs ~40
 // instructions per quotient and these kernels do three per element)
 struct VoxDecode {
@@ -519,6 +475,56 @@ __device__ __forceinline__ void decode_vox(const VoxDecode& q, long v, int& b, i
     t /= q.H;
     d = (int)(t % q.D);
     b = (int)(t / q.D);
+  }
+}
+
+// ---- stem: BatchNorm + ReLU + MaxPool3d(3,2,1) without materialising the normalised 64-channel volume.
+// y = relu(z * sc + sh) with sc = rstd * gamma, sh = beta - mean * sc  (recomputed wherever it is needed)
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
+  return make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), fmaxf(fmaf(v.z, sc.z, sh.z), 0.f),
+                     fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+}
+
+__global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restrict__ z, float4* __restrict__ p, int B, int D,
+                                                          int H, int W, int C4, const float4* __restrict__ sc,
+                                                          const float4* __restrict__ sh, VoxDecode vq, int c4_shift) {
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * Do * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+    int c, ow, oh, od, b;
+    if (vq.sw >= 0 && c4_shift >= 0) {  // pooled extents and C4 are powers of two: shifts instead of five divisions
+      c = (int)(i & (C4 - 1));
+      decode_vox(vq, i >> c4_shift, b, od, oh, ow);
+    } else {
+      c = (int)(i % C4);
+      long t = i / C4;
+      ow = (int)(t % Wo);
+      t /= Wo;
+      oh = (int)(t % Ho);
+      t /= Ho;
+      od = (int)(t % Do);
+      b = (int)(t / Do);
+    }
+    const float4 a = sc[c], s0 = sh[c];
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // ReLU output is >= 0 and every window holds a valid voxel
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = 2 * od + dz;
+      if ((unsigned)zz >= (unsigned)D) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = 2 * oh + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = 2 * ow + dx;
+          if ((unsigned)xx >= (unsigned)W) continue;
+          const float4 v = bn_relu4(z[((((long)b * D + zz) * H + yy) * W + xx) * C4 + c], a, s0);
+          m.x = fmaxf(m.x, v.x);
+          m.y = fmaxf(m.y, v.y);
+          m.z = fmaxf(m.z, v.z);
+          m.w = fmaxf(m.w, v.w);
+        }
+      }
+    }
+    p[i] = m;
   }
 }
 
@@ -972,7 +978,7 @@ extern "C" int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B
   HP_PROF("stem_bn_relu_pool_fwd", st);
   const long n = (long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(k_bn_relu_pool3_fwd, dim3(grid_for(n)), dim3(ET), 0, st, (const float4*)z, (float4*)pooled, B, D, H, W, C / 4,
-                     (const float4*)sc, (const float4*)sh);
+                     (const float4*)sc, (const float4*)sh, make_decode(D / 2, H / 2, W / 2), is_pow2(C / 4) ? ilog2(C / 4) : -1);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
