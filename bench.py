@@ -97,9 +97,38 @@ def algorithmic_work(kernel: str, T: int, N: int, B: int):
     return table.get(kernel)
 
 
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def csrc_sha() -> str:
+    """sha1 over the kernel sources: a PMC profile is only quoted on a bench line produced by the SAME kernels."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "hiddenpose_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "hiddenpose_amd", "csrc", "*.cpp")) +
+                    glob.glob(os.path.join(ROOT, "hiddenpose_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(threads: int):
-    """Oracle train step (fwd + losses + bwd + Adam) on ONE 128x128x128 cube = 1/4 of a
-    128x128x512 sample; value is scaled to 128x128x512 samples/s."""
+    """BASELINE.md section 3 protocol: the oracle (CPU restatement of the reference) on ONE 128x128x128 cube
+    (= 1/4 of a 128x128x512 sample, `scaled_from`), 1 warm-up + 3 timed iterations, median; legs: forward only
+    (eval, no_grad) and the full train step (forward + losses + backward + Adam).  `value` is the train-step leg scaled
+    to 128x128x512 samples/s, i.e. the same unit as the GPU line."""
+    import statistics
+
     from hiddenpose_amd import testing as hpt
     from hiddenpose_amd.config import make_cfg
     from hiddenpose_amd.NlosPose import NlosPose
@@ -115,15 +144,32 @@ def cpu_baseline(threads: int):
     vol = hpt.synthetic_vol(B, T, N)
     joints = hpt.synthetic_joints(B, T // 2).reshape(B, -1)
     opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
-    t0 = time.perf_counter()
-    loss, *_ = O.train_loss(meas, vol, joints, sd, k)
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": round(0.25 / dt, 6), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 cube of 128x128x128 (1/4 of a 128x128x512 sample), oracle fwd+loss+bwd+Adam, {dt:.1f} s, "
-                      f"scaled x1/4; torch CPU fp32, {threads} threads"}
+
+    def train():
+        t0 = time.perf_counter()
+        loss, *_ = O.train_loss(meas, vol, joints, sd, k)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    def fwd():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.train_loss(meas, vol, joints, sd, k)
+        return time.perf_counter() - t0
+
+    fwd()
+    t_fwd = statistics.median(fwd() for _ in range(3))
+    train()
+    t_train = statistics.median(train() for _ in range(3))
+    return {"value": round(0.25 / t_train, 6), "unit": "samples/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model_string(), "protocol": "1 warm-up + 3 timed, median",
+            "scaled_from": "one 128x128x128 cube = 1/4 of a 128x128x512 sample (times x4)",
+            "train_step_s_per_cube": round(t_train, 3), "forward_s_per_cube": round(t_fwd, 3),
+            "forward_value": round(0.25 / t_fwd, 6),
+            "sample": f"1 cube of 128x128x128, oracle (torch CPU fp32, {threads} threads): forward + losses {t_fwd:.2f} s, "
+                      f"forward + losses + backward + Adam {t_train:.2f} s (medians of 3 after 1 warm-up); value = train leg / 4"}
 
 
 def bench_sformer(args):
@@ -291,6 +337,35 @@ def bench_highres(args):
                      "ms_per_direction": round(lct_ms / lct_calls, 3) if lct_ms else None}}), flush=True)
 
 
+def quick_native(args, local, note):
+    """The same train step at the reference's native shape (128x128x128, batch 4), 1 warm-up + 3 timed steps."""
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.NlosPose import NlosPose
+    from hiddenpose_amd.train_epoch import build_training, train_step
+
+    T, N, B = WORKLOADS["native"]
+    dev = torch.device("cuda", local)
+    cfg = make_cfg(T, N, device=local, conv_precision=args.conv_precision)
+    model = NlosPose(cfg).to(dev).train()
+    criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410).to(dev)
+    vol = hpt.synthetic_vol(B, T, N, seed=1).to(dev)
+    joints = hpt.synthetic_joints(B, T // 2, seed=2).to(dev)
+    train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, None)
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    note(f"extra: native 128^3 batch {B}: {1e3 * dt / steps:.1f} ms/step")
+    return {"workload": f"NlosPose train step, {N}x{N}x{T} (reference-native shape), batch {B}, {args.conv_precision}",
+            "ms_per_step": round(1e3 * dt / steps, 3), "value": round(B * steps / dt, 3), "unit": "samples/s", "steps": steps,
+            "warmup": 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,8 +379,15 @@ def main():
                          "The headline metric (configs[1]) is fp32, the default.")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--wgrad-stream", action="store_true",
-                    help="opt-in: weight gradients on a second HIP stream (hip_ops.set_wgrad_async); single GPU only. "
+                    help="opt-in: weight gradients on a second HIP stream (hip_ops.set_wgrad_async). "
                          "Kernels then overlap, so per-kernel times and the roofline object describe contended launches.")
+    ap.add_argument("--dp-algo", default=os.environ.get("HP_DP_ALGO", "all_reduce"), choices=["all_reduce", "rs_ag", "a2a"],
+                    help="gradient exchange per bucket (data_parallel.GradBucketReducer): RCCL all-reduce, "
+                         "reduce-scatter + all-gather, or direct all-to-all reduce-scatter + all-gather")
+    ap.add_argument("--dp-wire", default=os.environ.get("HP_DP_WIRE", "auto"), choices=["auto", "fp32", "bf16"],
+                    help="dtype on the wire for the gradient exchange; auto = bf16 in the bf16 convolution modes "
+                         "(BASELINE configs[2]), fp32 otherwise")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short 128^3 (reference-native shape) run reported under `extra`")
     args = ap.parse_args()
 
     if args.workload == "sformer":
@@ -364,7 +446,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, force_collectives=force) if (world > 1 or force) else None
+    wire = {"auto": torch.bfloat16 if bf16 else None, "fp32": None, "bf16": torch.bfloat16}[args.dp_wire]
+    reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, force_collectives=force, algo=args.dp_algo,
+                                wire_dtype=wire) if (world > 1 or force) else None
 
     # synthetic batch of this rank (different samples per rank), resident in HBM before timing
     meas = hpt.synthetic_meas(B, T, N, "transient", seed=410 + rank * B).to(dev)
@@ -431,7 +515,8 @@ def main():
                                    "accumulation) with fp32 LCT, U-Net, norms, losses and fp32 tensors in HBM" if bf16 else "fp32") + ", random-init weights"
                                    + (", weight gradients on a second stream (kernels overlap)" if args.wgrad_stream and world == 1 else ""),
                        "global_batch": B * world,
-                       "parallelism": f"dp{world}", "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
+                       "parallelism": f"dp{world}" + (f" ({args.dp_algo}, {'bf16' if wire is not None else 'fp32'} wire, "
+                                                      f"{args.bucket_mb:g} MB buckets)" if reducer is not None else ""), "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
                        "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
             "loss": round(float(loss.item()), 6),
         }
@@ -450,15 +535,19 @@ def main():
                         "gflop_per_step": round(conv[name] / 1e9, 1)}
                 # HBM bytes of this kernel family per step from the committed PMC passes (rocprofv3 --pmc
                 # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH x2 on gfx950); only valid for the same workload
-                pmc = os.path.join(ROOT, "profiles", "round1_t512_pmc_hbm_traffic.json")
+                pmc = os.path.join(ROOT, "profiles", "t512_pmc_hbm_traffic.json")
                 if args.workload == "t512" and B == 4 and not bf16 and os.path.exists(pmc):
                     fam = json.load(open(pmc))
                     key = name if name in fam else None
-                    if key:
+                    if fam.get("_csrc_sha") != csrc_sha():
+                        # the counters were collected on other kernels than the ones just timed: quote nothing
+                        roof["stale_profile"] = (f"profiles/t512_pmc_hbm_traffic.json was collected at csrc sha "
+                                                 f"{fam.get('_csrc_sha')}, this run is {csrc_sha()}: traffic not quoted")
+                    elif key:
                         per_step = n / args.steps
                         roof["traffic"] = round(fam[key] / per_step, 3)
                         roof["traffic_unit"] = ("GB of HBM per launch, mean over the family's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                                                "profiles/round1_t512_pmc_hbm_traffic.csv)")
+                                                "profiles/t512_pmc_hbm_traffic.json, same csrc sha)")
                         roof["traffic_gb_per_step"] = fam[key]
                         roof["gflop_per_launch"] = round(conv[name] / 1e9 / per_step, 1)
             elif work and n:
@@ -476,6 +565,13 @@ def main():
             line["mfma_tflops_by_kernel"] = {k: round(cf[k] * args.steps / (prof[k][1] / 1e3) / 1e12, 1)
                                              for k in sorted(cf) if k in prof and prof[k][1] > 0}
         line["roofline"] = roof
+        if world == 1 and args.workload == "t512" and not args.no_extra:
+            # SURVEY 8(d) names two shapes for configs[1]: the BASELINE-worded 128x128x512 cube (the headline above) and
+            # the reference's own training shape 128^3 (train.py:77-86); the second is reported here, same step, same batch
+            del step
+            model = optimizer = criterion = voxel_criterion = meas = vol = joints = None
+            torch.cuda.empty_cache()
+            line["extra"] = {"native_128": quick_native(args, local, note)}
         if world == 1 and not args.no_cpu_baseline:
             # the box's CPU share for one GPU is 16 cores: more threads than that only oversubscribe
             try:

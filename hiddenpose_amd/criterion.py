@@ -49,8 +49,16 @@ class DiceLoss(nn.Module):
 
 
 class BCEDiceLoss(nn.Module):
-    """BCEWithLogits(mean) + Dice over the whole batch (one fused reduction)."""
+    """BCEWithLogits(mean) + Dice over the whole batch (one fused reduction).
+
+    `global_batch=True` (data parallelism): the Dice sums are taken over every rank's samples, as the reference's
+    single process does over its whole batch (utils/criterion.py:358-368); with gradient averaging over ranks the
+    result is exactly the loss and gradient of the concatenated batch (hip_ops._BceDiceGlobal)."""
+
+    def __init__(self, global_batch: bool = False, group=None):
+        super().__init__()
+        self.global_batch, self.group = global_batch, group
 
     def forward(self, logits, targets):
         assert logits.shape == targets.shape
-        return ops.bce_dice(logits, targets)
+        return ops.bce_dice(logits, targets, global_batch=self.global_batch, group=self.group)

@@ -418,6 +418,20 @@ static int upload_twiddles(int L, float2** tw, float2** hs) {
 
 static bool supported_len(int L) { return is_pow2(L) && L >= 16 && L <= 1024; }
 
+// Plan management runs on the plan's device but leaves the caller's current device as it found it (a finalizer may
+// destroy a plan at any point of a multi-device process).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 template <int L, bool REAL_IN>
 static void launch_fwd(dim3 grid, hipStream_t st, const float* xr, const float2* in, float2* out, int batch, long vol,
                        PassGeom g, const float2* tw, const float2* hs, const BandDev& b) {
@@ -552,7 +566,7 @@ extern "C" int hp_lct_plan_create(hp_lct_plan** out, int T, int N, double bin_le
     return HP_ERR_NO_DEVICE;
   }
   HP_REQUIRE(device >= 0 && device < ndev, "hp_lct_plan_create: device %d out of range (%d devices)", device, ndev);
-  HP_CHECK_HIP(hipSetDevice(device));
+  DeviceGuard guard(device);
 
   hp_lct_plan* p = new hp_lct_plan();
   p->T = T;
@@ -631,7 +645,7 @@ extern "C" int hp_lct_plan_create(hp_lct_plan** out, int T, int N, double bin_le
 
 extern "C" int hp_lct_plan_destroy(hp_lct_plan* p) {
   if (!p) return HP_OK;
-  (void)hipSetDevice(p->device);
+  DeviceGuard guard(p->device);
   if (p->Hdev) (void)hipFree(p->Hdev);
   for (float2* q : {p->twT, p->hsT, p->twN, p->hsN})
     if (q) (void)hipFree(q);
@@ -664,7 +678,7 @@ extern "C" int hp_lct_plan_get_invpsf(const hp_lct_plan* p, float* re, float* im
   const int N2 = 2 * p->N, M2 = 2 * p->T;
   const size_t sl = (size_t)N2 * N2;
   std::vector<float2> h(sl * M2);
-  HP_CHECK_HIP(hipSetDevice(p->device));
+  DeviceGuard guard(p->device);
   HP_CHECK_HIP(hipMemcpy(h.data(), p->Hdev, sizeof(float2) * sl * M2, hipMemcpyDeviceToHost));
   const double unscale = (double)M2 * N2 * N2;
   for (int at = 0; at < M2; ++at)

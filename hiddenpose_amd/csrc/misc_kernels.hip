@@ -285,10 +285,11 @@ __global__ void k_bce_dice_finish(const double* __restrict__ acc, long n, float 
 // dDice/dsig_i = (2 t_i U - (2 I + eps)) / U^2,  U = sum sig + sum t
 __global__ __launch_bounds__(MT) void k_bce_dice_bwd(const float* __restrict__ logit, const float* __restrict__ target,
                                                      const double* __restrict__ acc, const float* __restrict__ gl,
-                                                     float* __restrict__ dlogit, long n, float eps) {
+                                                     float* __restrict__ dlogit, long n, float eps, float dice_scale) {
   const double U = acc[2] + acc[3];
   const float invn = (float)(1.0 / (double)n);
-  const float c1 = (float)(2.0 / U), c0 = (float)((2.0 * acc[1] + (double)eps) / (U * U));
+  const float c1 = (float)((double)dice_scale * 2.0 / U);
+  const float c0 = (float)((double)dice_scale * (2.0 * acc[1] + (double)eps) / (U * U));
   const float g = gl[0];
   for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n; i += (long)gridDim.x * MT) {
     const float x = logit[i], t = target[i];
@@ -397,12 +398,35 @@ extern "C" int hp_bce_dice_forward(const float* logit, const float* target, long
   return HP_OK;
 }
 
-extern "C" int hp_bce_dice_backward(const float* logit, const float* target, const double* acc, const float* gloss,
-                                    float* dlogit, long n, float eps, void* stream) {
+extern "C" int hp_bce_dice_backward_scaled(const float* logit, const float* target, const double* acc, const float* gloss,
+                                           float* dlogit, long n, float eps, float dice_scale, void* stream) {
   HP_REQUIRE(logit && target && acc && gloss && dlogit && n > 0, "hp_bce_dice_backward: bad argument");
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("bce_dice_bwd", st);
-  hipLaunchKernelGGL(k_bce_dice_bwd, dim3(mgrid(n)), dim3(MT), 0, st, logit, target, acc, gloss, dlogit, n, eps);
+  hipLaunchKernelGGL(k_bce_dice_bwd, dim3(mgrid(n)), dim3(MT), 0, st, logit, target, acc, gloss, dlogit, n, eps, dice_scale);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_bce_dice_backward(const float* logit, const float* target, const double* acc, const float* gloss,
+                                    float* dlogit, long n, float eps, void* stream) {
+  return hp_bce_dice_backward_scaled(logit, target, acc, gloss, dlogit, n, eps, 1.0f, stream);
+}
+
+extern "C" int hp_bce_dice_partial(const float* logit, const float* target, long n, double* acc, void* stream) {
+  HP_REQUIRE(logit && target && acc && n > 0, "hp_bce_dice_partial: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 4, st));
+  HP_PROF("bce_dice_fwd", st);
+  hipLaunchKernelGGL(k_bce_dice_reduce, dim3(mgrid(n)), dim3(MT), 0, st, logit, target, acc, n);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_bce_dice_finalize(const double* acc, long n, float eps, float* loss, void* stream) {
+  HP_REQUIRE(acc && loss && n > 0, "hp_bce_dice_finalize: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bce_dice_finish, dim3(1), dim3(1), 0, st, acc, n, eps, loss);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

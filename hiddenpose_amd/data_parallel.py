@@ -1,17 +1,31 @@
 """Data-parallel training of NlosPose: one process per GPU, gradients averaged with
-bucketed all-reduce over RCCL/xGMI (torch.distributed backend "nccl" on ROCm).
+bucketed collectives over RCCL/xGMI (torch.distributed backend "nccl" on ROCm).
 
 The reference is single-GPU (a commented-out nn.DataParallel at train.py:111); the path
 shards by SAMPLE only: every stage is per-sample except BatchNorm batch
 statistics (kept per device, as on the reference's single device) and the batch-global
-Dice term, which `all_reduce_dice_terms` makes exact across ranks with one 3-scalar
-all-reduce.
+Dice term (utils/criterion.py:358-368), which `criterion.BCEDiceLoss(global_batch=True)`
+makes exact across ranks with one 3-scalar all-reduce inside the loss (forward) and no
+collective at all in its backward (hip_ops._BceDiceGlobal).
 
 Design for xGMI (point-to-point links, ring collectives are per-link bound): few large
 buckets in reverse registration order -- posenet layer4 + head hold ~80 % of the 353 MB
-and finish first in backward -- each all-reduced asynchronously on RCCL's own stream as
-soon as its last gradient has been accumulated, so the transfer hides under the rest of
+and finish first in backward -- each reduced on a dedicated communication stream as soon
+as its last gradient has been accumulated, so the transfer hides under the rest of
 backward.  Gradients live as views into the flat bucket buffers: no pack/unpack copies.
+
+Three exchange algorithms (`algo`), to be A/B-ed on the first 8-GPU run:
+  "all_reduce"  one RCCL all-reduce per bucket (RCCL picks ring/tree);
+  "rs_ag"       reduce_scatter_tensor + all_gather_into_tensor per bucket;
+  "a2a"         direct reduce-scatter: all_to_all_single puts shard j of every rank on rank j over
+                its own xGMI link (all 7 links busy, 1/8 of the bucket per link instead of the
+                ring's 7/8 through one), local sum, then all_gather_into_tensor.
+`wire_dtype=torch.bfloat16` sends bf16 on the wire (BASELINE configs[2]: 176 MB instead of
+353 MB per step); the buckets themselves and the sum handed to Adam stay fp32.
+
+Side-stream weight gradients (hip_ops.set_wgrad_async): those gradients are accumulated into
+the bucket views on the side stream and reported through hip_ops._side_grad_listeners; a
+bucket's collective is queued behind BOTH streams, so the overlap mode stays on under DP.
 """
 from __future__ import annotations
 
@@ -20,12 +34,19 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+ALGOS = ("all_reduce", "rs_ag", "a2a")
+
 
 class GradBucketReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 64.0, group: Optional[dist.ProcessGroup] = None,
-                 broadcast_from: int = 0, force_collectives: bool = False):
+                 broadcast_from: int = 0, force_collectives: bool = False, algo: str = "all_reduce",
+                 wire_dtype: Optional[torch.dtype] = None):
+        if algo not in ALGOS:
+            raise ValueError(f"algo must be one of {ALGOS}, got {algo!r}")
         self.module = module
         self.group = group
+        self.algo = algo
+        self.wire_dtype = wire_dtype
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force_collectives: issue the (trivial) collectives even at world size 1, to rehearse the code path
         self._active = self.world > 1 or (force_collectives and dist.is_initialized())
@@ -49,7 +70,8 @@ class GradBucketReducer:
         self._bucket_of = {}
         for bi, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
-            flat = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            n_pad = -(-n // self.world) * self.world          # rs_ag / a2a split a bucket into `world` equal shards
+            flat = torch.zeros(n_pad, dtype=bucket[0].dtype, device=bucket[0].device)
             o = 0
             for p in bucket:
                 p.grad = flat[o:o + p.numel()].view_as(p)
@@ -57,15 +79,17 @@ class GradBucketReducer:
                 self._bucket_of[p] = bi
             self.flat.append(flat)
         self._pending = [0] * len(self.buckets)
-        self._handles = []
+        self._arrived = set()
         self._hooks = []
-        # gradients are accumulated into the bucket views on the main stream as soon as autograd gets them: the
-        # opt-in side-stream weight gradient (hip_ops.set_wgrad_async) would be read before it is written
-        from . import hip_ops
-        hip_ops.set_wgrad_async(False)
+        self._cuda = self.flat[0].is_cuda
+        self._comm_stream = torch.cuda.Stream(self.flat[0].device) if (self._cuda and self._active) else None
+        self._side = None
         if self._active:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            from . import hip_ops
+
+            hip_ops._side_grad_listeners.append(self._on_side_grad)
         self.begin_step()
 
     # -- per-step protocol: zero_grad() ; forward ; backward ; finish() ; optimizer.step()
@@ -76,18 +100,53 @@ class GradBucketReducer:
 
     def begin_step(self) -> None:
         self._pending = [len(b) for b in self.buckets]
-        self._handles = []
+        self._arrived = set()
+        self._side = None
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if p in self._arrived or p not in self._bucket_of:
+            return
+        self._arrived.add(p)
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
+    def _on_side_grad(self, p: torch.nn.Parameter, side_stream) -> None:
+        """A weight gradient was accumulated into its bucket view on hip_ops' side stream."""
+        self._side = side_stream
+        self._on_grad(p)
+
+    def _exchange(self, flat: torch.Tensor) -> None:
+        """Average `flat` over the group, in place; runs on the current (communication) stream."""
+        flat.div_(self.world)
+        buf = flat.to(self.wire_dtype) if (self.wire_dtype is not None and self.wire_dtype != flat.dtype) else flat
+        if self.algo == "all_reduce":
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            w = self.world
+            shard = torch.empty(buf.numel() // w, dtype=buf.dtype, device=buf.device)
+            if self.algo == "rs_ag":
+                dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                recv = torch.empty_like(buf)
+                dist.all_to_all_single(recv, buf, group=self.group)
+                torch.sum(recv.view(w, -1), dim=0, out=shard)
+            dist.all_gather_into_tensor(buf, shard, group=self.group)
+        if buf is not flat:
+            flat.copy_(buf)
+
     def _launch(self, bi: int) -> None:
         flat = self.flat[bi]
-        flat.div_(self.world)
-        self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._comm_stream is None:
+            self._exchange(flat)
+            return
+        cs = self._comm_stream
+        cs.wait_stream(torch.cuda.current_stream(flat.device))
+        if self._side is not None:
+            cs.wait_stream(self._side)
+        with torch.cuda.stream(cs):
+            self._exchange(flat)
 
     def finish(self) -> None:
         """Wait for every bucket (buckets whose parameters got no gradient this step are
@@ -97,19 +156,23 @@ class GradBucketReducer:
                 if left > 0:
                     self._pending[bi] = 0
                     self._launch(bi)
-            for h in self._handles:
-                h.wait()
-        self._handles = []
+            if self._comm_stream is not None:
+                torch.cuda.current_stream(self.flat[0].device).wait_stream(self._comm_stream)
 
     def remove_hooks(self) -> None:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        from . import hip_ops
+
+        if self._on_side_grad in hip_ops._side_grad_listeners:
+            hip_ops._side_grad_listeners.remove(self._on_side_grad)
 
 
 def all_reduce_dice_terms(inter: torch.Tensor, psum: torch.Tensor, tsum: torch.Tensor, group=None):
-    """Make the batch-global Dice score (utils/criterion.py:358-368) exact under data
-    parallelism: sums of sigma(x)t, sigma(x) and t over ALL ranks' samples."""
+    """Sums of sigma(x)t, sigma(x) and t over ALL ranks' samples (the batch-global Dice score of
+    utils/criterion.py:358-368).  Plain (non-differentiable) sums: hip_ops._BceDiceGlobal, which is what the training
+    path uses, derives its gradient from the global sums analytically and needs no collective in backward."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         v = torch.stack([inter, psum, tsum])
         dist.all_reduce(v, group=group)

@@ -1,11 +1,10 @@
 """Operator layer between the reference-shaped nn.Modules and libhiddenpose_hip.so.
 
-Every function here is one fused stage of the hot path.  A stage
-either calls a hand-written HIP kernel through the C ABI (wrapped in a
-torch.autograd.Function so that optimisers and torch.distributed stay stock), or --
-for rows whose kernel has not landed yet -- the stock PyTorch-ROCm device operator.
-`HIP_STAGES` / `ATEN_STAGES` say which is which; DESIGN.md tracks the same table.
-There is no CPU path: tensors must live on a HIP device.
+Every function here is one fused stage of the hot path: a hand-written
+HIP kernel called through the C ABI, wrapped in a torch.autograd.Function so that optimisers
+and torch.distributed stay stock.  `HIP_STAGES` lists the rows; `ATEN_STAGES` names the only
+stock device operator left on the path (Adam).  There is no CPU path: tensors must live on a
+HIP device.
 """
 from __future__ import annotations
 
@@ -14,7 +13,7 @@ import torch.nn.functional as F
 
 HIP_STAGES = {"feature_extraction", "lct_forward", "lct_backward", "normalize_feature", "unet3d", "posenet3d_50",
               "softmax_integral", "bce_dice"}
-ATEN_STAGES = {"weighted_mse on (B,72) joints", "Adam"}
+ATEN_STAGES = {"Adam"}
 
 
 def _need_cuda(x: torch.Tensor, what: str) -> None:
@@ -385,6 +384,19 @@ class GradLink:
         self.arrivals = 0
         self.mask = None   # byte mask gating `g` (identity shortcut: g is the block's raw output gradient)
 
+    def take(self):
+        """One consumer of the block input runs its backward: returns (addend, mask, last).  The link is consumed
+        by ONE backward pass over the graph; a second pass (retain_graph=True, torch.autograd.grad twice) would
+        silently drop the parked partial sums, so it raises instead."""
+        if self.arrivals <= 0:
+            raise RuntimeError("hiddenpose_amd: a Bottleneck's fused gradient link was already consumed -- a second "
+                               "backward pass over the same graph (retain_graph=True) is not supported; run the "
+                               "forward again")
+        self.arrivals -= 1
+        addend, self.g = self.g, None
+        mask, self.mask = self.mask, None
+        return addend, mask, self.arrivals == 0
+
 
 class ResLink:
     """Joins the shortcut unit (downsample conv + BN) of a Bottleneck to the unit that adds its output as the
@@ -470,6 +482,7 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
     # rest of backward on the main one (join_side_streams() before the first reader of the gradients).
     main = torch.cuda.current_stream(x.device)
     side.wait_stream(main)
+    accumulate = w.is_leaf and w.grad is not None
     with torch.cuda.stream(side):
         sst = _stream(x)
         dwp = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -480,10 +493,25 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
         else:
             dw = torch.empty_like(w)
             _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), sst), "hp_conv3d_unpack_wgrad")
+        if accumulate:
+            # `w.grad` already holds something (gradient accumulation over micro-batches, zero_grad(set_to_none=False),
+            # or a view into a GradBucketReducer bucket): autograd's AccumulateGrad would read `dw` on the MAIN stream
+            # before the side stream has written it.  The sum is therefore taken here, on the side stream, and autograd
+            # gets no gradient for this weight; whoever listens for gradients (the bucket reducer) is told directly.
+            with torch.no_grad():
+                w.grad.add_(dw)
     for t in (x, dz, w):
         t.record_stream(side)
+    if accumulate:
+        for fn in _side_grad_listeners:   # called with the MAIN stream current: a listener orders itself behind both
+            fn(w, side)
+        return dx, None
     dw.record_stream(main)
     return dx, dw
+
+
+# callables (parameter, side_stream) run after a weight gradient was ACCUMULATED on the side stream (see above)
+_side_grad_listeners = []
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -593,10 +621,7 @@ class _ConvBnAct(torch.autograd.Function):
             addend = addend_mask = None
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:
-                link_in.arrivals -= 1
-                addend, link_in.g = link_in.g, None
-                addend_mask, link_in.mask = link_in.mask, None
-                last = link_in.arrivals == 0
+                addend, addend_mask, last = link_in.take()
             dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask)
             if not last:           # first of two convolutions reading the block input: park the partial sum
                 link_in.g, dx = dx, None
@@ -819,5 +844,49 @@ class _BceDice(torch.autograd.Function):
         return d, None, None
 
 
-def bce_dice(logits, targets, eps=1e-9):
+class _BceDiceGlobal(torch.autograd.Function):
+    """BCEDice whose Dice sums span every rank's samples (utils/criterion.py:358-368 is batch-global).  The value
+    returned on a rank is local-BCE-mean + 1 - Dice_global, so the mean over ranks IS the single-process loss of the
+    concatenated batch; the gradient w.r.t. the local logits is scaled so that AVERAGING gradients over ranks
+    (GradBucketReducer) gives exactly that loss's gradient.  One all-reduce of 3 doubles in forward, none in backward."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, eps, group):
+        import torch.distributed as dist
+
+        _need_cuda(logits, "bce_dice")
+        logits, targets = logits.contiguous(), targets.contiguous().float()
+        L = _lib.lib()
+        acc = torch.empty(4, dtype=torch.float64, device=logits.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        world = 1
+        with torch.cuda.device(logits.device):
+            st = _stream(logits)
+            _lib.check(L.hp_bce_dice_partial(logits.data_ptr(), targets.data_ptr(), logits.numel(), acc.data_ptr(), st),
+                       "hp_bce_dice_partial")
+            if dist.is_available() and dist.is_initialized():
+                world = dist.get_world_size(group)
+                dist.all_reduce(acc[1:4], group=group)
+            _lib.check(L.hp_bce_dice_finalize(acc.data_ptr(), logits.numel(), eps, loss.data_ptr(), _stream(logits)),
+                       "hp_bce_dice_finalize")
+        ctx.save_for_backward(logits, targets, acc)
+        ctx.eps, ctx.world = eps, world
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        logits, targets, acc = ctx.saved_tensors
+        d = torch.empty_like(logits)
+        gl = gl.reshape(1).contiguous().float()
+        with torch.cuda.device(logits.device):
+            _lib.check(_lib.lib().hp_bce_dice_backward_scaled(logits.data_ptr(), targets.data_ptr(), acc.data_ptr(),
+                                                              gl.data_ptr(), d.data_ptr(), logits.numel(), ctx.eps,
+                                                              float(ctx.world), _stream(logits)),
+                       "hp_bce_dice_backward_scaled")
+        return d, None, None, None
+
+
+def bce_dice(logits, targets, eps=1e-9, global_batch=False, group=None):
+    if global_batch:
+        return _BceDiceGlobal.apply(logits, targets, eps, group)
     return _BceDice.apply(logits, targets, eps)

@@ -29,7 +29,11 @@ def seed_everything(seed: int = 410) -> None:
 def build_training(cfg, model):
     """Losses, optimiser and schedule exactly as train.py:129-141."""
     criterion = L2JointLocationLoss(output_3d=True)
-    voxel_criterion = BCEDiceLoss()
+    # under torch.distributed the batch is the union of every rank's samples: Dice is batch-global in the reference
+    import torch.distributed as dist
+
+    voxel_criterion = BCEDiceLoss(global_batch=dist.is_available() and dist.is_initialized()
+                                  and dist.get_world_size() > 1)
     optimizer = get_optimizer(cfg, model)
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, cfg.TRAIN.LR_STEP, cfg.TRAIN.LR_FACTOR)
     return criterion, voxel_criterion, optimizer, scheduler
@@ -67,6 +71,23 @@ def checkpoint_dict(model, optimizer, lr_scheduler, epoch, global_iter_num=None)
     if global_iter_num is not None:
         d["global_iter_num"] = global_iter_num
     return d
+
+
+def save_checkpoint(state: dict, path: str) -> None:
+    """Rank 0 only (every rank holds the same replica), written to a temporary file and renamed so that a reader --
+    or a second writer -- never sees a truncated checkpoint; the other ranks wait until the file exists."""
+    import os
+
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    if not distributed or dist.get_rank() == 0:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        tmp = f"{path}.tmp.{os.getpid()}"
+        torch.save(state, tmp)
+        os.replace(tmp, path)
+    if distributed:
+        dist.barrier()
 
 
 @torch.no_grad()
@@ -108,9 +129,8 @@ def train_epoch(cfg, train_loader, model, criterion, voxel_criterion, optimizer,
         epoch_sum += loss
         steps += 1
         if global_iter_num % 10000 == 0:
-            os.makedirs(save_model_dir, exist_ok=True)
-            torch.save(checkpoint_dict(model, optimizer, lr_scheduler, epoch, global_iter_num),
-                       os.path.join(save_model_dir, f"NlosPose_dict_iter{global_iter_num}.pth"))
+            save_checkpoint(checkpoint_dict(model, optimizer, lr_scheduler, epoch, global_iter_num),
+                            os.path.join(save_model_dir, f"NlosPose_dict_iter{global_iter_num}.pth"))
         if global_iter_num % 100 == 0:
             mean100 = float(window) / 100.0
             window.zero_()

@@ -271,6 +271,15 @@ int hp_bce_dice_forward(const float* logit, const float* target, long n, float e
                         void* stream);
 int hp_bce_dice_backward(const float* logit, const float* target, const double* acc, const float* gloss, float* dlogit,
                          long n, float eps, void* stream);
+/* The same loss with the Dice sums taken over a batch that spans several devices (data parallelism; the reference's
+ * Dice is batch-global, utils/criterion.py:358-368): `partial` leaves {sum bce, sum sig t, sum sig, sum t} of the
+ * LOCAL n elements in acc[0..3]; the caller sums acc[1..3] over all ranks (one 3-scalar all-reduce); `finalize`
+ * gives loss = acc[0]/n + 1 - (2 acc[1] + eps)/(acc[2] + acc[3]); `backward_scaled` multiplies the Dice part of the
+ * gradient by dice_scale (= world size when the gradients are afterwards AVERAGED over ranks). */
+int hp_bce_dice_partial(const float* logit, const float* target, long n, double* acc, void* stream);
+int hp_bce_dice_finalize(const double* acc, long n, float eps, float* loss, void* stream);
+int hp_bce_dice_backward_scaled(const float* logit, const float* target, const double* acc, const float* gloss,
+                                float* dlogit, long n, float eps, float dice_scale, void* stream);
 
 /* ------------------------------------------------------------------------
  * NlosPoseSformer inference (models/NlosPoseSformer.py; BASELINE config 5).  Linear layers use

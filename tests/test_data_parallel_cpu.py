@@ -24,7 +24,23 @@ def _model():
                                torch.nn.Linear(32, 5))
 
 
-def _worker(rank, world, port, out):
+def _dice_rank_loss_and_grad(x, t, world, eps=1e-9):
+    """The arithmetic of hip_ops._BceDiceGlobal / hp_bce_dice_{partial,finalize,backward_scaled} restated in torch:
+    local sums, ONE all-reduce of the three Dice sums, loss = local BCE mean + 1 - Dice_global, analytic gradient with
+    the Dice part scaled by the world size (gradients are averaged over ranks afterwards)."""
+    s = torch.sigmoid(x)
+    n = x.numel()
+    acc = torch.stack([torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="sum"), (s * t).sum(), s.sum(),
+                       t.sum()]).double()
+    dist.all_reduce(acc[1:4])
+    U = acc[2] + acc[3]
+    loss = acc[0] / n + 1.0 - (2.0 * acc[1] + eps) / U
+    c1, c0 = world * 2.0 / U, world * (2.0 * acc[1] + eps) / (U * U)
+    grad = (s - t) / n - (t * c1 - c0) * s * (1 - s)
+    return loss, grad
+
+
+def _worker(rank, world, port, out, algo="all_reduce", wire=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hiddenpose_amd.data_parallel import GradBucketReducer, all_reduce_dice_terms
@@ -34,7 +50,7 @@ def _worker(rank, world, port, out):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
-    red = GradBucketReducer(model, bucket_mb=0.002)  # ~2 KB buckets -> several buckets
+    red = GradBucketReducer(model, bucket_mb=0.002, algo=algo, wire_dtype=wire)  # ~2 KB buckets -> several buckets
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     g = torch.Generator().manual_seed(100 + rank)
     for step in range(2):
@@ -48,17 +64,26 @@ def _worker(rank, world, port, out):
             grads0 = [p.grad.clone() for p in model.parameters()]
         opt.step()
     i, p_, t = all_reduce_dice_terms(torch.tensor(1.0 + rank), torch.tensor(2.0 + rank), torch.tensor(3.0 + rank))
-    out[rank] = {"nb": len(red.buckets), "grads0": grads0, "params": [p.detach().clone() for p in model.parameters()],
+    # batch-global Dice (utils/criterion.py:358-368) under data parallelism: rank-local logits / targets
+    gd = torch.Generator().manual_seed(500 + rank)
+    xl = torch.randn(3, 40, generator=gd, dtype=torch.float64)
+    tl = (torch.rand(3, 40, generator=gd) < 0.3).double()
+    dl, dg = _dice_rank_loss_and_grad(xl, tl, world)
+    dist.all_reduce(dl)
+    dl /= world              # what averaging the per-rank losses reports
+    out[rank] = {"dice_loss": dl.item(), "dice_grad": dg / world,   # / world: the reducer's gradient averaging
+"nb": len(red.buckets), "grads0": grads0, "params": [p.detach().clone() for p in model.parameters()],
                  "dice": (i.item(), p_.item(), t.item()),
                  "views": all(p.grad.data_ptr() >= red.flat[red._bucket_of[p]].data_ptr() for p in model.parameters())}
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2():
+@pytest.mark.parametrize("algo,wire", [("all_reduce", None), ("rs_ag", None), ("a2a", None), ("all_reduce", torch.bfloat16)])
+def test_bucketed_allreduce_world2(algo, wire):
     world, port = 2, _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, algo, wire), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
     assert r0["nb"] > 1 and r0["views"] and r1["views"]
     # expected step-0 gradient: average of the two ranks' local gradients from rank 0's weights
@@ -72,12 +97,26 @@ def test_bucketed_allreduce_world2():
         gs = [p.grad.clone() for p in model.parameters()]
         exp = gs if exp is None else [a + b for a, b in zip(exp, gs)]
     exp = [e / world for e in exp]
+    tol = dict(atol=1e-7, rtol=1e-5) if wire is None else dict(atol=2e-3, rtol=2e-2)   # bf16 on the wire: 8 bits
     for a, b, e in zip(r0["grads0"], r1["grads0"], exp):
         assert torch.allclose(a, b, atol=0, rtol=0)
-        assert torch.allclose(a, e, atol=1e-7, rtol=1e-5)
+        assert torch.allclose(a, e, **tol)
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
     assert r0["dice"] == r1["dice"] == (3.0, 5.0, 7.0)
+    # the reference's loss on the CONCATENATED batch, by autograd, in one process
+    xs, ts = [], []
+    for rank in range(world):
+        gd = torch.Generator().manual_seed(500 + rank)
+        xs.append(torch.randn(3, 40, generator=gd, dtype=torch.float64))
+        ts.append((torch.rand(3, 40, generator=gd) < 0.3).double())
+    x = torch.cat(xs).requires_grad_(True)
+    t = torch.cat(ts)
+    p = torch.sigmoid(x)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(x, t) + 1.0 - (2.0 * (p * t).sum() + 1e-9) / (p.sum() + t.sum())
+    ref.backward()
+    assert abs(r0["dice_loss"] - ref.item()) < 1e-12 and abs(r1["dice_loss"] - ref.item()) < 1e-12
+    assert torch.allclose(torch.cat([r0["dice_grad"], r1["dice_grad"]]), x.grad, atol=1e-14, rtol=1e-10)
 
 
 def test_single_process_reducer_is_transparent():

@@ -1,0 +1,176 @@
+"""The data-parallel machinery on the GPU with HIP-kernel gradients: GradBucketReducer over a world-1 RCCL group
+(every collective is issued for real: all-reduce, reduce-scatter + all-gather, all-to-all; bf16 wire; side-stream
+weight gradients), the batch-global Dice kernels, and the accumulation safety of the side-stream weight gradient.
+The N > 1 arithmetic (averaging, broadcast, Dice sums over ranks) is covered by tests/test_data_parallel_cpu.py (gloo)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from hiddenpose_amd import hip_ops as ops
+from hiddenpose_amd import testing as hpt
+from hiddenpose_amd.config import make_cfg
+from hiddenpose_amd.NlosPose import NlosPose
+from hiddenpose_amd.train_epoch import build_training, compute_loss
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+T = N = 32
+B = 2
+
+
+@pytest.fixture(scope="module")
+def rccl_world1():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+def _inputs():
+    return (hpt.synthetic_meas(B, T, N).cuda(), hpt.synthetic_vol(B, T, N).cuda(), hpt.synthetic_joints(B, T // 2).cuda())
+
+
+def _model():
+    cfg = make_cfg(T, N)
+    m = NlosPose(cfg)
+    hpt.fill_module(m)
+    return cfg, m.cuda().train()
+
+
+def _plain_step_grads():
+    cfg, model = _model()
+    criterion, voxel_criterion, _, _ = build_training(cfg, model)
+    loss, *_ = compute_loss(model, criterion, voxel_criterion, *_inputs())
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.fixture(scope="module")
+def plain():
+    return _plain_step_grads()
+
+
+@pytest.mark.parametrize("algo,wire,side", [("all_reduce", None, False), ("rs_ag", None, False), ("a2a", None, False),
+                                            ("all_reduce", torch.bfloat16, False), ("all_reduce", None, True),
+                                            ("a2a", torch.bfloat16, True)])
+def test_reducer_on_rccl_with_hip_gradients(rccl_world1, plain, algo, wire, side):
+    """One NlosPose train-step backward through GradBucketReducer(force_collectives=True): gradients (views into the
+    flat buckets, exchanged over RCCL on the communication stream) equal the reducer-free step."""
+    from hiddenpose_amd.data_parallel import GradBucketReducer
+
+    loss0, g0 = plain
+    cfg, model = _model()
+    criterion, voxel_criterion, _, _ = build_training(cfg, model)
+    prev = ops.set_wgrad_async(side)
+    red = GradBucketReducer(model, bucket_mb=16.0, force_collectives=True, algo=algo, wire_dtype=wire)
+    try:
+        assert len(red.buckets) > 3
+        for _ in range(2):   # the second pass re-uses zeroed buckets
+            loss, *_ = compute_loss(model, criterion, voxel_criterion, *_inputs())
+            red.zero_grad()
+            loss.backward()
+            red.finish()
+        torch.cuda.synchronize()
+    finally:
+        red.remove_hooks()
+        ops.set_wgrad_async(prev)
+    assert abs(loss.item() / loss0 - 1) < 1e-6
+    tol = 1e-6 if wire is None else 8e-3
+    for k, p in model.named_parameters():
+        assert p.grad.data_ptr() >= red.flat[red._bucket_of[p]].data_ptr()
+        ref = g0[k]
+        if ref.abs().max() == 0:
+            assert p.grad.abs().max() == 0, k
+        else:
+            assert rel_l2(p.grad, ref) < tol, (k, rel_l2(p.grad, ref))
+
+
+def test_side_stream_wgrad_accumulates_safely(plain):
+    """with set_wgrad_async(True), a second backward into existing .grad tensors (micro-batch
+    accumulation, zero_grad(set_to_none=False)) must not read a weight gradient the side stream has not written yet:
+    two accumulated backward passes give exactly twice the single-pass gradient."""
+    _, g0 = plain
+    cfg, model = _model()
+    criterion, voxel_criterion, _, _ = build_training(cfg, model)
+    prev = ops.set_wgrad_async(True)
+    try:
+        for _ in range(2):
+            loss, *_ = compute_loss(model, criterion, voxel_criterion, *_inputs())
+            loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_wgrad_async(prev)
+    for k in ["pose_net.conv1.weight", "pose_net.layer1.0.conv2.weight", "pose_net.layer3.2.conv1.weight",
+              "pose_net.head.features.0.weight", "pose_net.head.features.9.weight", "pose_net.bn1.weight"]:
+        p = dict(model.named_parameters())[k]
+        assert rel_l2(p.grad, 2 * g0[k]) < 1e-6, k
+
+
+def test_second_backward_over_one_graph_fails_loudly():
+    cfg, model = _model()
+    criterion, voxel_criterion, _, _ = build_training(cfg, model)
+    loss, *_ = compute_loss(model, criterion, voxel_criterion, *_inputs())
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()
+
+
+def test_global_dice_kernels_two_rank_emulation():
+    """hp_bce_dice_partial / finalize / backward_scaled: two 'ranks' (halves of a batch) whose Dice sums are added as
+    the 3-scalar all-reduce would; the mean of the rank losses and the averaged gradients equal the single-kernel
+    loss / gradient of the concatenated batch (utils/criterion.py:358-385 is batch-global)."""
+    import ctypes as C
+
+    from hiddenpose_amd import _lib
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(4, 4096, generator=g) * 2).cuda().requires_grad_(True)
+    t = (torch.rand(4, 4096, generator=g) < 0.1).float().cuda()
+    ref = ops.bce_dice(x, t)
+    ref.backward()
+    st = torch.cuda.current_stream().cuda_stream
+    halves = [(x.detach()[:2].contiguous(), t[:2].contiguous()), (x.detach()[2:].contiguous(), t[2:].contiguous())]
+    accs = []
+    for xa, ta in halves:
+        acc = torch.empty(4, dtype=torch.float64, device="cuda")
+        _lib.check(L.hp_bce_dice_partial(xa.data_ptr(), ta.data_ptr(), xa.numel(), acc.data_ptr(), st), "partial")
+        accs.append(acc)
+    tot = accs[0][1:4] + accs[1][1:4]
+    losses, grads = [], []
+    one = torch.ones(1, device="cuda")
+    for (xa, ta), acc in zip(halves, accs):
+        acc[1:4] = tot
+        loss = torch.empty(1, device="cuda")
+        _lib.check(L.hp_bce_dice_finalize(acc.data_ptr(), xa.numel(), 1e-9, loss.data_ptr(), st), "finalize")
+        d = torch.empty_like(xa)
+        _lib.check(L.hp_bce_dice_backward_scaled(xa.data_ptr(), ta.data_ptr(), acc.data_ptr(), one.data_ptr(), d.data_ptr(),
+                                                 xa.numel(), 1e-9, 2.0, st), "backward_scaled")
+        losses.append(loss)
+        grads.append(d / 2)       # gradient averaging over the two ranks
+    assert abs((losses[0] + losses[1]).item() / 2 / ref.item() - 1) < 1e-6
+    assert rel_l2(torch.cat(grads), x.grad) < 1e-6
+
+
+def test_global_dice_module_world1(rccl_world1):
+    from hiddenpose_amd.criterion import BCEDiceLoss
+
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 8192, generator=g).cuda()
+    t = (torch.rand(2, 8192, generator=g) < 0.05).float().cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    la = BCEDiceLoss()(xa, t)
+    lb = BCEDiceLoss(global_batch=True)(xb, t)
+    la.backward()
+    lb.backward()
+    assert abs(la.item() - lb.item()) < 1e-7
+    assert rel_l2(xb.grad, xa.grad) < 1e-7

@@ -20,7 +20,7 @@ from torch.utils.data import DataLoader
 from hiddenpose_amd.cli import build_config, load_checkpoint, parse_args
 from hiddenpose_amd.NlosPose import NlosPose
 from hiddenpose_amd.nlos_pose_dataloader import NlosPoseDataset
-from hiddenpose_amd.train_epoch import build_training, checkpoint_dict, seed_everything, train_epoch
+from hiddenpose_amd.train_epoch import build_training, checkpoint_dict, save_checkpoint, seed_everything, train_epoch
 
 
 def _collate(batch):
@@ -36,6 +36,9 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", str(args.device)))
     args.device = (0 if os.environ.get("HP_SHARE_GPU") else local) if world > 1 else args.device
     cfg = build_config(args)
+    # must be in the environment before the first HIP call initialises the runtime (dmabuf IPC for RCCL)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(cfg.DEVICE)
     reducer = None
     if world > 1:
@@ -43,8 +46,6 @@ def main(argv=None):
 
         from hiddenpose_amd.data_parallel import GradBucketReducer
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("HP_DIST_BACKEND", "nccl")  # "gloo" only to rehearse on a box without several GPUs
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", cfg.DEVICE))
@@ -94,9 +95,8 @@ def main(argv=None):
         if rank == 0:
             dt = time.time() - t0
             print(f"epoch {epoch} used {dt}, mean loss {mean_loss}, left {dt * (cfg.TRAIN.END_EPOCH - epoch - 1) / 3600} hours")
-            os.makedirs(save_model_dir, exist_ok=True)
-            torch.save(checkpoint_dict(model, optimizer, lr_scheduler, epoch),
-                       os.path.join(save_model_dir, f"NlosPose_final_dict_{epoch}.pth"))
+        save_checkpoint(checkpoint_dict(model, optimizer, lr_scheduler, epoch),
+                        os.path.join(save_model_dir, f"NlosPose_final_dict_{epoch}.pth"))
     if rank == 0:
         os.makedirs(save_model_dir, exist_ok=True)
         with open(os.path.join(save_model_dir, "NlosPose.log"), "w", encoding="utf-8") as fh:
