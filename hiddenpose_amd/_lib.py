@@ -59,13 +59,15 @@ SIGNATURES = {
     "hp_stem_bn_relu_pool_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_stem_bn_relu_pool_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _i, _fp, _fp, _vp, _vp]),
     "hp_dconv3_forward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_dconv3_forward_fused": (_i, [_fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _vp]),
     "hp_dconv3_backward_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "hp_dconv3_backward_data": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_dconv3_backward_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "hp_dconv3_backward_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_groupnorm_workspace_bytes": (_sz, [_i, _i]),
     "hp_groupnorm_relu_forward": (_i, [_fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, C.c_float, _fp, _fp, _vp, _vp]),
-    "hp_groupnorm_relu_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "hp_groupnorm_relu_forward_v2": (_i, [_fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, C.c_float, _vp, _fp, _fp, _fp, _fp, _vp, _vp]),
+    "hp_groupnorm_relu_backward_v2": (_i, [_fp, _fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_maxpool3d_k2_forward": (_i, [_fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_maxpool3d_k2_backward": (_i, [_fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_upsample_trilinear2x_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -521,22 +521,291 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Forward / data-gradient 3x3x3 convolution on v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// The 4x4x1 kernel above needs one shifted ds_read_b32 per MFMA for 256 MACs: with the weights in registers it is
+// bound by the LDS read rate (128 B/clk/CU) at about half the matrix rate.  Here one 16x16x4 MFMA takes
+//     rows    m = 16 consecutive voxels of an x-run,
+//     K       k = 4 input channels of a chunk (single-channel layers: the 3 dy taps),
+//     columns n = dz * 4 + co   (3 z-taps x 4 output channels = 12 of 16 columns),
+// i.e. 768 useful MACs per 256-byte LDS read (3x the 4x4x1 kernel) at 3/4 of the matrix rate.  The product of
+// INPUT plane z' with the dz-th z-tap belongs to OUTPUT plane z' - dz + pad, so a workgroup that slides along z keeps,
+// per tile, the partial sums of the two output planes still waiting for input (q0, q1: lanes n < 4) and folds the
+// three column groups of each new product into them with two DPP row shifts:
+//     out[z'-2+pad] = q1 + P[dz=2]   (complete: bias / residual / leaky / GroupNorm statistics, 16-byte stores)
+//     q1 = q0 + P[dz=1],  q0 = P[dz=0]
+// Only ONE input plane is live in LDS at a time (two slots: the next plane is fetched into registers during the
+// multiply phase and parked afterwards, one barrier per plane); channel stride and row pitch are = 16 (mod 32) floats
+// so that the four 16-lane segments of an operand read fall on disjoint banks.
+constexpr int F_TY = 8, F_TX = 64, F_PX = 80, F_ROWS = F_TY + 2;
+constexpr int F_CS = F_ROWS * F_PX + 16;  // 816 = 16 (mod 32)
+constexpr int F_MAXC = 8;                 // input channels staged per launch
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// CIN1: single input channel, K slots carry the dy taps.  Otherwise cin_here (<= 8) channels in chunks of 4.
+template <int PADMODE, bool CIN1>
+__global__ __launch_bounds__(256, 2) void k_dconv3_f16(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ res,
+                                                        float* __restrict__ y, double* __restrict__ stats, int cin, int c_base,
+                                                        int cin_here, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                        int pad, long wsco, long wsci, int flip, int tiles_x, int tiles_y,
+                                                        int zchunk, int accumulate, float slope) {
+  constexpr int NCH = CIN1 ? 1 : F_MAXC;
+  constexpr int SLOT = NCH * F_CS;
+  __shared__ float img[2 * SLOT];
+  __shared__ float sred[4][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, ln = lane & 15;  // K slot / column (A: row = ln) of this lane's operands
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y, cog = blockIdx.z;
+  const int x0 = bx * F_TX, y0 = by * F_TY;
+  const int zb = bz * zchunk, ze = min(Do, zb + zchunk);
+  const long ics = (long)Di * Hi * Wi, ocs = (long)Do * Ho * Wo;
+  const int nchunk = CIN1 ? 1 : (cin_here + 3) / 4;
+
+  // B operand (weights), in registers for the whole walk: lane (k = lk, n = ln) -> w[co][ci][dz][dy][dx]
+  const int wdz = ln >> 2, wco = cog * 4 + (ln & 3);
+  const bool wn_ok = ln < 12 && wco < cout;
+  float wreg[CIN1 ? 3 : 18];
+  if constexpr (CIN1) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int tap = (wdz * 3 + min(lk, 2)) * 3 + dx;
+      wreg[dx] = (wn_ok && lk < 3) ? w[(long)wco * wsco + (long)c_base * wsci + (flip ? 26 - tap : tap)] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ci = 4 * j + lk;
+        const int tap = wdz * 9 + t;
+        wreg[j * 9 + t] = (wn_ok && ci < cin_here) ? w[(long)wco * wsco + (long)(c_base + ci) * wsci + (flip ? 26 - tap : tap)] : 0.f;
+      }
+  }
+
+  // staging map: element e = tid + 256 k (k < 3) of ONE channel's [10 rows][66 cols] halo image; the same three
+  // (row, column) slots serve every channel, so the tables cost 6 registers whatever the channel count
+  constexpr int PER_CH = F_ROWS * 66;
+  constexpr int SKC = (PER_CH + 255) / 256;  // 3
+  constexpr int SK = NCH * SKC;
+  int soff[SKC], loff[SKC];
+  unsigned smask = 0;
+  const float* xb = x + ((long)b * cin + c_base) * ics;
+  const int nstage = CIN1 ? 1 : cin_here;
+#pragma unroll
+  for (int k = 0; k < SKC; ++k) {
+    const int e = tid + 256 * k;
+    const int ly = e / 66, lx = e - ly * 66;
+    int yy = y0 + ly - pad, xx = x0 + lx - pad;
+    bool ok = e < PER_CH;
+    if (PADMODE == 1) {
+      yy = min(max(yy, 0), Hi - 1);
+      xx = min(max(xx, 0), Wi - 1);
+    } else {
+      ok = ok && (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
+    }
+    soff[k] = ok ? (int)((long)yy * Wi + xx) : 0;
+    loff[k] = e < PER_CH ? ly * F_PX + lx : -1;
+    smask |= ok ? (1u << k) : 0u;
+  }
+  auto stage_load = [&](int zin, float (&v)[SK]) {
+    int zz = zin;
+    bool zok = (unsigned)zz < (unsigned)Di;
+    if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
+    const float* src = xb + (long)zz * Hi * Wi;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int k = 0; k < SKC; ++k)
+        v[c * SKC + k] = (zok && c < nstage && ((smask >> k) & 1u)) ? src[(long)c * ics + soff[k]] : 0.f;
+  };
+  auto stage_store = [&](int slot, const float (&v)[SK]) {
+    float* dst = img + slot * SLOT;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int k = 0; k < SKC; ++k)
+        if (loff[k] >= 0) dst[c * F_CS + loff[k]] = v[c * SKC + k];
+  };
+  // columns 66..79 and the 16-float tail of a channel are never read with a non-zero weight except through
+  // shifted reads of tiles at the right edge (x offsets <= 65): nothing to clear.
+
+  f32x4 q0[8], q1[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) q0[t] = q1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
+
+  const int zfirst = zb - pad, zlast = ze - 1 - pad + 2;
+  if (zb < ze) {
+    float v0[SK];
+    stage_load(zfirst, v0);
+    stage_store(0, v0);
+  }
+  __syncthreads();
+  // this lane's operand base inside a slot
+  const int abase = CIN1 ? (2 * wave + min(lk, 2)) * F_PX + ln : lk * F_CS + (2 * wave) * F_PX + ln;
+  const bool vec_ok = (Wo & 3) == 0;
+  const int oco = cog * 4 + (ln & 3);
+  const bool st_lane = ln < 4 && oco < cout;
+  const float bv = (st_lane && bias && !accumulate) ? bias[oco] : 0.f;
+  for (int zp = zfirst, it = 0; zb < ze && zp <= zlast; ++zp, ++it) {
+    float nxt[SK];
+    if (zp < zlast) stage_load(zp + 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* a0 = img + (it & 1) * SLOT + abase;
+    f32x4 P[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) P[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (CIN1) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[(t >> 2) * F_PX + (t & 3) * 16 + dx], wreg[dx], P[t], 0, 0, 0);
+    } else {
+      for (int j = 0; j < nchunk; ++j) {
+        const float* aj = a0 + j * 4 * F_CS;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float wv = j ? wreg[9 + dy * 3 + dx] : wreg[dy * 3 + dx];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              P[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[((t >> 2) + dy) * F_PX + (t & 3) * 16 + dx], wv, P[t], 0, 0, 0);
+          }
+      }
+    }
+    const int zo = zp - 2 + pad;  // the output plane completed by this input plane
+    const bool zst = zo >= zb && zo < ze;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x4 d;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float p = P[t][i];
+        d[i] = q1[t][i] + dpp_mov<0x108>(p);        // row_shl:8 -> columns dz = 2
+        q1[t][i] = q0[t][i] + dpp_mov<0x104>(p);    // row_shl:4 -> columns dz = 1
+        q0[t][i] = p;
+      }
+      const int oy = y0 + 2 * wave + (t >> 2), ox = x0 + (t & 3) * 16 + 4 * lk;
+      if (zst && st_lane && oy < Ho && ox < Wo) {
+        const long o = ((long)b * cout + oco) * ocs + ((long)zo * Ho + oy) * Wo + ox;
+        if (vec_ok) {  // Wo % 4 == 0: the four voxels are inside the row and 16-byte aligned
+          float4 r4 = make_float4(d[0] + bv, d[1] + bv, d[2] + bv, d[3] + bv);
+          if (accumulate) {
+            const float4 pv = *reinterpret_cast<const float4*>(y + o);
+            r4.x += pv.x; r4.y += pv.y; r4.z += pv.z; r4.w += pv.w;
+          }
+          if (res) {
+            const float4 rv = *reinterpret_cast<const float4*>(res + o);
+            r4.x += rv.x; r4.y += rv.y; r4.z += rv.z; r4.w += rv.w;
+          }
+          if (slope != 1.0f) {
+            r4.x = r4.x > 0.f ? r4.x : r4.x * slope; r4.y = r4.y > 0.f ? r4.y : r4.y * slope;
+            r4.z = r4.z > 0.f ? r4.z : r4.z * slope; r4.w = r4.w > 0.f ? r4.w : r4.w * slope;
+          }
+          s1 += (r4.x + r4.y) + (r4.z + r4.w);
+          s2 += (r4.x * r4.x + r4.y * r4.y) + (r4.z * r4.z + r4.w * r4.w);
+          *reinterpret_cast<float4*>(y + o) = r4;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (ox + i < Wo) {
+              float r = d[i] + bv;
+              if (accumulate) r += y[o + i];
+              if (res) r += res[o + i];
+              if (slope != 1.0f) r = r > 0.f ? r : r * slope;
+              s1 += r;
+              s2 += r * r;
+              y[o + i] = r;
+            }
+        }
+      }
+    }
+    if (zp < zlast) stage_store((it + 1) & 1, nxt);
+    __syncthreads();
+  }
+  if (stats) {
+    // per output channel: lanes (ln = co, any lk) of all four waves
+    s1 += __shfl_xor(s1, 16);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    if (lane < 4) {
+      sred[wave][lane] = s1;
+      sred[wave][4 + lane] = s2;
+    }
+    __syncthreads();
+    if (tid < 8) {
+      const int co = cog * 4 + (tid & 3);
+      if (co < cout) {
+        const float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+        atomicAdd(stats + ((long)b * cout + co) * 2 + (tid >> 2), (double)v);
+      }
+    }
+  }
+}
+
 // generic entry: y (B,cout,Do,Ho,Wo) = conv3(x (B,cin,Di,Hi,Wi)) with weight(co,ci,tap) = w[co*wsco + ci*wsci + tap']
-static int run_dconv(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int Di, int Hi,
-                     int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci, int flip, int padmode,
-                     hipStream_t st) {
+static bool use_old_dconv() {
+  static const bool v = [] {
+    const char* e = getenv("HP_DCONV_4X4");
+    return e && atoi(e) != 0;
+  }();
+  return v;
+}
+
+static int run_dconv(const float* x, const float* w, const float* bias, const float* res, float* y, double* stats, float slope,
+                     int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
+                     int flip, int padmode, hipStream_t st) {
   const int tiles_x = (Wo + WG_TX - 1) / WG_TX, tiles_y = (Ho + WG_TY - 1) / WG_TY, cog_n = (cout + 3) / 4;
   const long cols = (long)tiles_x * tiles_y * B * cog_n;
   int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (1536 + cols - 1) / cols));
   const int zchunk = (Do + zsplit - 1) / zsplit;
   zsplit = (Do + zchunk - 1) / zchunk;
   dim3 grid((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)B, (unsigned)cog_n);
-  if (padmode)
-    hipLaunchKernelGGL((k_dconv3_mfma<1>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
-                       wsci, flip, tiles_x, tiles_y, zchunk);
-  else
-    hipLaunchKernelGGL((k_dconv3_mfma<0>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
-                       wsci, flip, tiles_x, tiles_y, zchunk);
+  if (use_old_dconv() && !res && !stats && slope == 1.0f) {
+    if (padmode)
+      hipLaunchKernelGGL((k_dconv3_mfma<1>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
+                         wsci, flip, tiles_x, tiles_y, zchunk);
+    else
+      hipLaunchKernelGGL((k_dconv3_mfma<0>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
+                         wsci, flip, tiles_x, tiles_y, zchunk);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+  }
+  static_assert(F_TY == WG_TY && F_TX == WG_TX, "both kernels share the workgroup tiling");
+  if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * cout, st));
+  for (int c_base = 0; c_base < cin; c_base += F_MAXC) {
+    const int here = std::min(F_MAXC, cin - c_base);
+    const bool last = c_base + here >= cin;
+    const int acc = c_base > 0 ? 1 : 0;
+    // residual / activation / statistics belong to the complete sum: the last channel block applies them
+    const float* r = last ? res : nullptr;
+    double* sp = last ? stats : nullptr;
+    const float sl = last ? slope : 1.0f;
+#define HP_F16_LAUNCH(PM, C1)                                                                                              \
+  hipLaunchKernelGGL((k_dconv3_f16<PM, C1>), grid, dim3(256), 0, st, x, w, bias, r, y, sp, cin, c_base, here, cout, Di, Hi, Wi, \
+                     Do, Ho, Wo, pad, wsco, wsci, flip, tiles_x, tiles_y, zchunk, acc, sl)
+    if (cin == 1) {
+      if (padmode) HP_F16_LAUNCH(1, true); else HP_F16_LAUNCH(0, true);
+    } else {
+      if (padmode) HP_F16_LAUNCH(1, false); else HP_F16_LAUNCH(0, false);
+    }
+#undef HP_F16_LAUNCH
+  }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
@@ -550,7 +819,16 @@ extern "C" int hp_dconv3_forward(const float* x, const float* w, const float* bi
   HP_REQUIRE(x && w && y && B > 0 && cin > 0 && cout > 0, "hp_dconv3_forward: bad argument");
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("dconv3_fwd", st);
-  return run_dconv(x, w, bias, y, B, cin, cout, D, H, W, D, H, W, 1, (long)cin * 27, 27, 0, replicate_pad, st);
+  return run_dconv(x, w, bias, nullptr, y, nullptr, 1.0f, B, cin, cout, D, H, W, D, H, W, 1, (long)cin * 27, 27, 0, replicate_pad, st);
+}
+
+extern "C" int hp_dconv3_forward_fused(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                       double* stats, int B, int cin, int cout, int D, int H, int W, int replicate_pad,
+                                       float slope, void* stream) {
+  HP_REQUIRE(x && w && y && B > 0 && cin > 0 && cout > 0, "hp_dconv3_forward_fused: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("dconv3_fwd", st);
+  return run_dconv(x, w, bias, residual, y, stats, slope, B, cin, cout, D, H, W, D, H, W, 1, (long)cin * 27, 27, 0, replicate_pad, st);
 }
 
 extern "C" size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad) {
@@ -564,13 +842,13 @@ extern "C" int hp_dconv3_backward_data(const float* gy, const float* w, float* g
   // gx[ci] = sum_co corr(gy[co], flipped w[co][ci]): roles of the channel strides swap
   if (!replicate_pad) {
     HP_PROF("dconv3_dgrad", st);
-    return run_dconv(gy, w, nullptr, gx, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st);
+    return run_dconv(gy, w, nullptr, nullptr, gx, nullptr, 1.0f, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st);
   }
   HP_REQUIRE(workspace, "hp_dconv3_backward_data: replicate padding needs the workspace");
   float* dpad = (float*)workspace;
   {
     HP_PROF("dconv3_dgrad", st);
-    int rc = run_dconv(gy, w, nullptr, dpad, B, cout, cin, D, H, W, D + 2, H + 2, W + 2, 2, 27, (long)cin * 27, 1, 0, st);
+    int rc = run_dconv(gy, w, nullptr, nullptr, dpad, nullptr, 1.0f, B, cout, cin, D, H, W, D + 2, H + 2, W + 2, 2, 27, (long)cin * 27, 1, 0, st);
     if (rc) return rc;
   }
   const long total = (long)B * cin * D * H * W;

@@ -22,6 +22,14 @@
 //    into the middle one; the heaviest pass (filter) streams contiguous rows.
 //  * backward = the same pipeline with conj(invpsf) and the two band operators
 //    swapped (adjoint; mtxi = mtx^T).
+//  * a LONE volume (batch 1, or the last volume of an odd batch) has no partner to share a complex
+//    volume with.  It takes the Hermitian route instead: the T-axis spectrum of real data satisfies
+//    X(2T - f) = conj X(f), so only the T + 1 planes f = 0..T are kept ("compact rows") and every later
+//    pass -- H, W . filter . W^-1, H^-1 -- runs on half the rows and reads half of invpsf: 136 V bytes
+//    instead of the 272 V a half-empty pair would move.  Inside the T passes two adjacent real columns
+//    (w, w+1) ride through one complex FFT and are untangled / re-entangled in LDS
+//    (E_a = (Z(k) + conj Z(-k))/2, E_b = (Z(k) - conj Z(-k))/2i), so the T pass costs the FFT work of a
+//    pair pass and its global accesses are 64-byte (real) / 128-byte (complex) row segments.
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -51,6 +59,10 @@ struct hp_lct_plan {
   float2* Hdev = nullptr;         // [2T][2N][2N] permuted, scaled
   float2 *twT = nullptr, *hsT = nullptr, *twN = nullptr, *hsN = nullptr;
   hp::BandDev fwd_in, fwd_out, bwd_in, bwd_out;
+  // lone-volume (Hermitian) path: natural T-frequency k -> position after fft_dif<T>, and compact row -> row of Hdev
+  uint16_t* posT = nullptr;
+  int32_t* crow = nullptr;
+  bool force_lone = false;  // every volume on the lone route (long T: its T passes move 64/128-byte row segments)
 };
 
 namespace hp {
@@ -294,12 +306,224 @@ __global__ __launch_bounds__(NT) void k_axis_inv(const float2* __restrict__ in, 
   }
 }
 
+
+// twiddles of the L-point transform read from the half-step table hs[p] = exp(-i pi p / L) (one LDS table instead
+// of two: the 1024-point lone-volume tile leaves room for exactly one)
+struct TwFromHalf {
+  const float2* hs;
+  int L;
+  __device__ __forceinline__ float2 operator()(int p) const {
+    const int q = 2 * p;
+    if (q < L) return hs[q];
+    const float2 v = hs[q - L];
+    return make_float2(-v.x, -v.y);
+  }
+};
+
+template <int L, int WT, int LD, typename TW>
+__device__ __forceinline__ void fft_dif_f(float2* s, TW tw, int tid) {
+#pragma unroll
+  for (int n = L; n >= 4; n >>= 2) {
+    const int m = n >> 2;
+    const int tstep = L / n;
+    for (int b = tid; b < (L / 4) * WT; b += NT) {
+      const int col = b % WT, bf = b / WT;
+      const int j = bf % m, blk = bf / m;
+      float2* p = s + (blk * n + j) * LD + col;
+      float2 a0 = p[0], a1 = p[m * LD], a2 = p[2 * m * LD], a3 = p[3 * m * LD];
+      float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+      float2 t3 = make_float2(d.y, -d.x);
+      float2 y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+      if (m > 1) {
+        y1 = cmul(y1, tw(tstep * j));
+        y2 = cmul(y2, tw(tstep * 2 * j));
+        y3 = cmul(y3, tw(tstep * 3 * j));
+      }
+      p[0] = y0;
+      p[m * LD] = y1;
+      p[2 * m * LD] = y2;
+      p[3 * m * LD] = y3;
+    }
+    __syncthreads();
+  }
+  if constexpr ((L & 0x55555555) == 0) {
+    for (int b = tid; b < (L / 2) * WT; b += NT) {
+      const int col = b % WT, blk = b / WT;
+      float2* p = s + (blk * 2) * LD + col;
+      float2 a0 = p[0], a1 = p[LD];
+      p[0] = cadd(a0, a1);
+      p[LD] = csub(a0, a1);
+    }
+    __syncthreads();
+  }
+}
+
+template <int L, int WT, int LD, typename TW>
+__device__ __forceinline__ void fft_dit_f(float2* s, TW tw, int tid) {
+  if constexpr ((L & 0x55555555) == 0) {
+    for (int b = tid; b < (L / 2) * WT; b += NT) {
+      const int col = b % WT, blk = b / WT;
+      float2* p = s + (blk * 2) * LD + col;
+      float2 a0 = p[0], a1 = p[LD];
+      p[0] = cadd(a0, a1);
+      p[LD] = csub(a0, a1);
+    }
+    __syncthreads();
+  }
+  constexpr int n0 = ((L & 0x55555555) == 0) ? 8 : 4;
+#pragma unroll
+  for (int n = n0; n <= L; n <<= 2) {
+    const int m = n >> 2;
+    const int tstep = L / n;
+    for (int b = tid; b < (L / 4) * WT; b += NT) {
+      const int col = b % WT, bf = b / WT;
+      const int j = bf % m, blk = bf / m;
+      float2* p = s + (blk * n + j) * LD + col;
+      float2 a0 = p[0], a1 = p[m * LD], a2 = p[2 * m * LD], a3 = p[3 * m * LD];
+      if (m > 1) {
+        a1 = cmulc(a1, tw(tstep * j));
+        a2 = cmulc(a2, tw(tstep * 2 * j));
+        a3 = cmulc(a3, tw(tstep * 3 * j));
+      }
+      float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+      float2 t3 = make_float2(-d.y, d.x);
+      p[0] = cadd(t0, t2);
+      p[m * LD] = cadd(t1, t3);
+      p[2 * m * LD] = csub(t0, t2);
+      p[3 * m * LD] = csub(t1, t3);
+    }
+    __syncthreads();
+  }
+}
+
+// Lone-volume T passes.  Tile: L time samples x WT complex columns = 2 WT adjacent real columns (w even in re, w+1
+// in im).  Compact rows: c = k (even bins f = 2k, k = 0..L/2), then c = L/2 + 1 + k (odd bins f = 2k+1, k < L/2).
+template <int L, int WT>
+__global__ __launch_bounds__(NT) void k_axis_fwd_t_lone(const float* __restrict__ x, float2* __restrict__ out, long plane,
+                                                       const float2* __restrict__ hs, const uint16_t* __restrict__ pos,
+                                                       const int32_t* __restrict__ boff, const int32_t* __restrict__ bidx,
+                                                       const float* __restrict__ bval) {
+  constexpr int EPT = (L * WT) / NT;
+  static_assert(EPT >= 1 && (L * WT) % NT == 0, "tile must cover the workgroup");
+  __shared__ float2 s[L * WT];
+  __shared__ float2 shs[L];
+  __shared__ uint16_t spos[L];
+  const int tid = threadIdx.x;
+  const long col0 = (long)blockIdx.x * (2 * WT);  // first real column (flattened h*N + w) of this tile
+  for (int i = tid; i < L; i += NT) {
+    shs[i] = hs[i];
+    spos[i] = pos[i];
+  }
+  float2 u[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + k * NT, n = e / WT, col = e % WT;
+    s[e] = *reinterpret_cast<const float2*>(x + (long)n * plane + col0 + 2 * col);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + k * NT, n = e / WT, col = e % WT;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int t = boff[n]; t < boff[n + 1]; ++t) {
+      const float c = bval[t];
+      const float2 v = s[bidx[t] * WT + col];
+      acc.x += c * v.x;
+      acc.y += c * v.y;
+    }
+    u[k] = acc;
+  }
+  const TwFromHalf tw{shs, L};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT;
+      s[e] = q ? cmul(u[k], shs[n]) : u[k];
+    }
+    __syncthreads();
+    fft_dif_f<L, WT, WT>(s, tw, tid);
+    const int nk = q ? L / 2 : L / 2 + 1;
+    const int c0 = q ? L / 2 + 1 : 0;
+    for (int i = tid; i < nk * WT; i += NT) {
+      const int k = i / WT, col = i % WT;
+      const int kp = q ? (L - 1 - k) : ((L - k) & (L - 1));
+      const float2 za = s[spos[k] * WT + col], zb = s[spos[kp] * WT + col];
+      // column a = (Z(k) + conj Z(k'))/2, column b = (Z(k) - conj Z(k'))/(2i)
+      const float4 o = make_float4(0.5f * (za.x + zb.x), 0.5f * (za.y - zb.y), 0.5f * (za.y + zb.y), 0.5f * (zb.x - za.x));
+      *reinterpret_cast<float4*>(out + (long)(c0 + k) * plane + col0 + 2 * col) = o;
+    }
+  }
+}
+
+template <int L, int WT>
+__global__ __launch_bounds__(NT) void k_axis_inv_t_lone(const float2* __restrict__ in, float* __restrict__ y, long plane,
+                                                       const float2* __restrict__ hs, const uint16_t* __restrict__ pos,
+                                                       const int32_t* __restrict__ boff, const int32_t* __restrict__ bidx,
+                                                       const float* __restrict__ bval) {
+  constexpr int EPT = (L * WT) / NT;
+  __shared__ float2 s[L * WT];
+  __shared__ float2 shs[L];
+  __shared__ uint16_t spos[L];
+  const int tid = threadIdx.x;
+  const long col0 = (long)blockIdx.x * (2 * WT);
+  for (int i = tid; i < L; i += NT) {
+    shs[i] = hs[i];
+    spos[i] = pos[i];
+  }
+  const TwFromHalf tw{shs, L};
+  float2 acc[EPT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    __syncthreads();
+    const int nk = q ? L / 2 : L / 2 + 1;
+    const int c0 = q ? L / 2 + 1 : 0;
+    for (int i = tid; i < nk * WT; i += NT) {
+      const int k = i / WT, col = i % WT;
+      const int kp = q ? (L - 1 - k) : ((L - k) & (L - 1));
+      const float4 v = *reinterpret_cast<const float4*>(in + (long)(c0 + k) * plane + col0 + 2 * col);
+      // Z(k) = A + i B ;  Z(k') = conj A + i conj B  (A, B: spectra of the two real output columns)
+      if (kp == k) {
+        s[spos[k] * WT + col] = make_float2(v.x, v.z);  // self-conjugate bins are real: keep the real parts
+      } else {
+        s[spos[k] * WT + col] = make_float2(v.x - v.w, v.y + v.z);
+        s[spos[kp] * WT + col] = make_float2(v.x + v.w, v.z - v.y);
+      }
+    }
+    __syncthreads();
+    fft_dit_f<L, WT, WT>(s, tw, tid);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT;
+      acc[k] = q ? cadd(acc[k], cmulc(s[e], shs[n])) : s[e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) s[tid + k * NT] = acc[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + k * NT, n = e / WT, col = e % WT;
+    float2 a = make_float2(0.f, 0.f);
+    for (int t = boff[n]; t < boff[n + 1]; ++t) {
+      const float c = bval[t];
+      const float2 v = s[bidx[t] * WT + col];
+      a.x += c * v.x;
+      a.y += c * v.y;
+    }
+    *reinterpret_cast<float2*>(y + (long)n * plane + col0 + 2 * col) = a;
+  }
+}
+
 // Middle pass on contiguous rows of length L (the W axis), in place:
 //   row <- crop( F^-1( H . F( pad(row) ) ) ),  H read once, coalesced.
 template <int L, int RT>
 __global__ __launch_bounds__(NT) void k_axis_mid(float2* __restrict__ data, const float2* __restrict__ H,
                                                  long pair_stride, long rows_per_pair, int conj_h,
-                                                 const float2* __restrict__ tw, const float2* __restrict__ hs) {
+                                                 const float2* __restrict__ tw, const float2* __restrict__ hs,
+                                                 const int32_t* __restrict__ crow, int rows_per_plane) {
   constexpr int EPT = (L * RT) / NT;
   constexpr int LD = RT + 1;
   __shared__ float2 s[L * LD];
@@ -309,7 +533,9 @@ __global__ __launch_bounds__(NT) void k_axis_mid(float2* __restrict__ data, cons
   const int pair = blockIdx.z;
   const long row0 = (long)blockIdx.x * RT;
   float2* base = data + (long)pair * pair_stride + row0 * L;
-  const float2* hbase = H + row0 * (2 * L);
+  // lone-volume path: data plane c (compact row) uses plane crow[c] of H; a tile never straddles two planes
+  const long hrow0 = crow ? (long)crow[row0 / rows_per_plane] * rows_per_plane + row0 % rows_per_plane : row0;
+  const float2* hbase = H + hrow0 * (2 * L);
   for (int i = tid; i < L; i += NT) {
     stw[i] = tw[i];
     shs[i] = hs[i];
@@ -450,10 +676,28 @@ static void launch_inv(dim3 grid, hipStream_t st, const float2* in, float2* out,
 }
 template <int L>
 static void launch_mid(dim3 grid, hipStream_t st, float2* data, const float2* H, long pair_stride, long rows,
-                       int conj_h, const float2* tw, const float2* hs) {
+                       int conj_h, const float2* tw, const float2* hs, const int32_t* crow) {
   constexpr int RT = tile_width(L);
+  static_assert((2 * L) % RT == 0, "a row tile must stay inside one (2N)-row plane");
   HP_PROF("lct_axis_mid_w", st);
-  hipLaunchKernelGGL((k_axis_mid<L, RT>), grid, dim3(NT), 0, st, data, H, pair_stride, rows, conj_h, tw, hs);
+  hipLaunchKernelGGL((k_axis_mid<L, RT>), grid, dim3(NT), 0, st, data, H, pair_stride, rows, conj_h, tw, hs, crow, 2 * L);
+}
+
+static constexpr int lone_tile_width(int L) { return L <= 512 ? 16 : 8; }  // complex columns: 64 KB of LDS at most
+
+template <int L>
+static void launch_fwd_t_lone(hipStream_t st, const float* x, float2* out, long plane, const hp_lct_plan* p, const BandDev& b) {
+  constexpr int WT = lone_tile_width(L);
+  HP_PROF("lct_lone_fwd_t", st);
+  hipLaunchKernelGGL((k_axis_fwd_t_lone<L, WT>), dim3((unsigned)(plane / (2 * WT))), dim3(NT), 0, st, x, out, plane, p->hsT,
+                     p->posT, b.off, b.idx, b.val);
+}
+template <int L>
+static void launch_inv_t_lone(hipStream_t st, const float2* in, float* y, long plane, const hp_lct_plan* p, const BandDev& b) {
+  constexpr int WT = lone_tile_width(L);
+  HP_PROF("lct_lone_inv_t", st);
+  hipLaunchKernelGGL((k_axis_inv_t_lone<L, WT>), dim3((unsigned)(plane / (2 * WT))), dim3(NT), 0, st, in, y, plane, p->hsT,
+                     p->posT, b.off, b.idx, b.val);
 }
 
 #define HP_DISPATCH_LEN(L, CALL)                 \
@@ -468,6 +712,8 @@ static void launch_mid(dim3 grid, hipStream_t st, float2* data, const float2* H,
     default: break;                              \
   }
 
+static size_t lone_elems(const hp_lct_plan* p) { return (size_t)3 * (p->T + 1) * p->N * p->N; }  // float2 elements
+
 static int run_lct(const hp_lct_plan* p, const float* x, float* y, int batch, void* ws, size_t ws_bytes,
                    hipStream_t st, bool backward) {
   HP_REQUIRE(p && x && y && ws, "hp_lct: null argument");
@@ -477,7 +723,10 @@ static int run_lct(const hp_lct_plan* p, const float* x, float* y, int batch, vo
     set_error("hp_lct: workspace too small (%zu < %zu)", ws_bytes, need);
     return HP_ERR_WORKSPACE;
   }
-  const int T = p->T, N = p->N, P = (batch + 1) / 2;
+  const int T = p->T, N = p->N;
+  // complete pairs ride as complex volumes; a last odd volume takes the Hermitian (lone) route
+  const int P = p->force_lone ? 0 : batch / 2;
+  const int nlone = batch - 2 * P;
   const long vol = (long)T * N * N;
   float2* C1 = (float2*)ws;          // [P][2T][N][N]
   float2* C2 = C1 + (long)P * 2 * vol;  // [P][2T][2N][N]
@@ -486,28 +735,52 @@ static int run_lct(const hp_lct_plan* p, const float* x, float* y, int batch, vo
   const int wtT = tile_width(T), wtN = tile_width(N);
 
   PassGeom g;
-  // 1. T forward (+ band in)
-  g = PassGeom{0, 2 * vol, (int)((long)N * N / wtT), 0, 0, (long)N * N, (long)N * N};
-  HP_DISPATCH_LEN(T, (launch_fwd<LL, true>(dim3(g.chunks_per_outer, 1, P), st, x, nullptr, C1, batch, vol, g, p->twT,
-                                           p->hsT, bin)));
-  // 2. H forward
-  g = PassGeom{2 * vol, 4 * vol, N / wtN, (long)N * N, 2L * N * N, N, N};
-  HP_DISPATCH_LEN(N, (launch_fwd<LL, false>(dim3(2 * T * g.chunks_per_outer, 1, P), st, nullptr, C1, C2, batch, vol, g,
-                                            p->twN, p->hsN, bin)));
-  // 3. W forward . filter . W inverse (in place)
-  {
-    const long rows = 2L * T * 2 * N;
-    HP_DISPATCH_LEN(N, (launch_mid<LL>(dim3((unsigned)(rows / wtN), 1, P), st, C2, p->Hdev, 4 * vol, rows,
-                                       backward ? 1 : 0, p->twN, p->hsN)));
+  if (P > 0) {
+    const int pb = 2 * P;  // volumes on the pair route
+    // 1. T forward (+ band in)
+    g = PassGeom{0, 2 * vol, (int)((long)N * N / wtT), 0, 0, (long)N * N, (long)N * N};
+    HP_DISPATCH_LEN(T, (launch_fwd<LL, true>(dim3(g.chunks_per_outer, 1, P), st, x, nullptr, C1, pb, vol, g, p->twT,
+                                             p->hsT, bin)));
+    // 2. H forward
+    g = PassGeom{2 * vol, 4 * vol, N / wtN, (long)N * N, 2L * N * N, N, N};
+    HP_DISPATCH_LEN(N, (launch_fwd<LL, false>(dim3(2 * T * g.chunks_per_outer, 1, P), st, nullptr, C1, C2, pb, vol, g,
+                                              p->twN, p->hsN, bin)));
+    // 3. W forward . filter . W inverse (in place)
+    {
+      const long rows = 2L * T * 2 * N;
+      HP_DISPATCH_LEN(N, (launch_mid<LL>(dim3((unsigned)(rows / wtN), 1, P), st, C2, p->Hdev, 4 * vol, rows,
+                                         backward ? 1 : 0, p->twN, p->hsN, nullptr)));
+    }
+    // 4. H inverse
+    g = PassGeom{4 * vol, 2 * vol, N / wtN, 2L * N * N, (long)N * N, N, N};
+    HP_DISPATCH_LEN(N, (launch_inv<LL, false>(dim3(2 * T * g.chunks_per_outer, 1, P), st, C2, C1, nullptr, pb, vol, g,
+                                              p->twN, p->hsN, bout)));
+    // 5. T inverse (+ band out)
+    g = PassGeom{2 * vol, 0, (int)((long)N * N / wtT), 0, 0, (long)N * N, (long)N * N};
+    HP_DISPATCH_LEN(T, (launch_inv<LL, true>(dim3(g.chunks_per_outer, 1, P), st, C1, nullptr, y, pb, vol, g, p->twT,
+                                             p->hsT, bout)));
   }
-  // 4. H inverse
-  g = PassGeom{4 * vol, 2 * vol, N / wtN, 2L * N * N, (long)N * N, N, N};
-  HP_DISPATCH_LEN(N, (launch_inv<LL, false>(dim3(2 * T * g.chunks_per_outer, 1, P), st, C2, C1, nullptr, batch, vol, g,
-                                            p->twN, p->hsN, bout)));
-  // 5. T inverse (+ band out)
-  g = PassGeom{2 * vol, 0, (int)((long)N * N / wtT), 0, 0, (long)N * N, (long)N * N};
-  HP_DISPATCH_LEN(T, (launch_inv<LL, true>(dim3(g.chunks_per_outer, 1, P), st, C1, nullptr, y, batch, vol, g, p->twT,
-                                           p->hsT, bout)));
+  // lone volumes: T + 1 compact rows (Hermitian half of the T spectrum), same H / W passes on half the rows
+  float2* L1 = C1 + (long)P * 6 * vol;                       // [T+1][N][N]
+  float2* L2 = L1 + (long)(T + 1) * N * N;                   // [T+1][2N][N]
+  const long plane = (long)N * N;
+  for (int i = 0; i < nlone; ++i) {
+    const float* xi = x + (long)(2 * P + i) * vol;
+    float* yi = y + (long)(2 * P + i) * vol;
+    HP_DISPATCH_LEN(T, (launch_fwd_t_lone<LL>(st, xi, L1, plane, p, bin)));
+    g = PassGeom{0, 0, N / wtN, plane, 2 * plane, N, N};
+    HP_DISPATCH_LEN(N, (launch_fwd<LL, false>(dim3((T + 1) * g.chunks_per_outer, 1, 1), st, nullptr, L1, L2, 1, vol, g,
+                                              p->twN, p->hsN, bin)));
+    {
+      const long rows = (long)(T + 1) * 2 * N;
+      HP_DISPATCH_LEN(N, (launch_mid<LL>(dim3((unsigned)(rows / wtN), 1, 1), st, L2, p->Hdev, 0, rows, backward ? 1 : 0,
+                                         p->twN, p->hsN, p->crow)));
+    }
+    g = PassGeom{0, 0, N / wtN, 2 * plane, plane, N, N};
+    HP_DISPATCH_LEN(N, (launch_inv<LL, false>(dim3((T + 1) * g.chunks_per_outer, 1, 1), st, L2, L1, nullptr, 1, vol, g,
+                                              p->twN, p->hsN, bout)));
+    HP_DISPATCH_LEN(T, (launch_inv_t_lone<LL>(st, L1, yi, plane, p, bout)));
+  }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
@@ -601,6 +874,18 @@ extern "C" int hp_lct_plan_create(hp_lct_plan** out, int T, int N, double bin_le
   if ((rc = upload_band(p->bwd_out, bout))) return fail(rc);
   if ((rc = upload_twiddles(T, &p->twT, &p->hsT))) return fail(rc);
   if ((rc = upload_twiddles(N, &p->twN, &p->hsN))) return fail(rc);
+  {
+    const std::vector<int> freq = dif_position_to_freq(T);  // position -> natural frequency of the T-point DFT
+    std::vector<uint16_t> pos(T);
+    for (int q = 0; q < T; ++q) pos[freq[q]] = (uint16_t)q;
+    std::vector<int32_t> crow(T + 1);
+    for (int k = 0; k <= T / 2; ++k) crow[k] = pos[k];                        // even bins f = 2k: rows [0, T) of Hdev
+    for (int k = 0; k < T / 2; ++k) crow[T / 2 + 1 + k] = T + pos[k];          // odd bins  f = 2k+1: rows [T, 2T)
+    if ((rc = upload(&p->posT, pos))) return fail(rc);
+    if ((rc = upload(&p->crow, crow))) return fail(rc);
+    const char* env = getenv("HP_LCT_FORCE_LONE");
+    p->force_lone = env ? atoi(env) != 0 : false;
+  }
 
   // inverse PSF spectrum, permuted to the DIF/DIT bin order of the device passes and
   // pre-scaled by 1/(2T.2N.2N); built slice by slice (threads over kz) in pinned-size chunks.
@@ -649,6 +934,8 @@ extern "C" int hp_lct_plan_destroy(hp_lct_plan* p) {
   if (p->Hdev) (void)hipFree(p->Hdev);
   for (float2* q : {p->twT, p->hsT, p->twN, p->hsN})
     if (q) (void)hipFree(q);
+  if (p->posT) (void)hipFree(p->posT);
+  if (p->crow) (void)hipFree(p->crow);
   free_band(p->fwd_in);
   free_band(p->fwd_out);
   free_band(p->bwd_in);
@@ -659,8 +946,9 @@ extern "C" int hp_lct_plan_destroy(hp_lct_plan* p) {
 
 extern "C" size_t hp_lct_workspace_bytes(const hp_lct_plan* p, int batch) {
   if (!p || batch < 1) return 0;
-  const size_t P = (size_t)(batch + 1) / 2;
-  return P * 6 * (size_t)p->T * p->N * p->N * sizeof(float2);
+  const size_t P = p->force_lone ? 0 : (size_t)batch / 2;
+  const size_t nlone = (size_t)batch - 2 * P;
+  return (P * 6 * (size_t)p->T * p->N * p->N + (nlone ? hp::lone_elems(p) : 0)) * sizeof(float2);
 }
 
 extern "C" int hp_lct_forward(const hp_lct_plan* p, const float* x, float* y, int batch, void* ws, size_t ws_bytes,

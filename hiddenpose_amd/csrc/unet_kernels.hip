@@ -110,27 +110,31 @@ __global__ __launch_bounds__(UT) void k_affine_relu(const float* __restrict__ z,
 }
 
 // ---- GroupNorm backward.  g = dy * [y > 0];  per plane: S1 = sum g, S2 = sum g * z
-__global__ __launch_bounds__(UT) void k_gn_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ y,
-                                                      const float* __restrict__ z, double* __restrict__ acc, long V) {
+// The ReLU mask is rebuilt from z with the forward's own expression (fmaf(z, scale, shift) > 0), so the normalised
+// tensor y is not read back: two streams per pass instead of three.
+__global__ __launch_bounds__(UT) void k_gn_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ z,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      double* __restrict__ acc, long V) {
   __shared__ float sh[2 * UT / 64];
   const long plane = blockIdx.y;
+  const float fa = scale[plane], fc = shift[plane];
   const float4* pd = (const float4*)(dy + plane * V);
-  const float4* py = (const float4*)(y + plane * V);
   const float4* pz = (const float4*)(z + plane * V);
   const long n4 = V / 4;
   float s = 0.f, q = 0.f;
   for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
-    const float4 d = pd[i], yy = py[i], zz = pz[i];
-    const float g0 = yy.x > 0.f ? d.x : 0.f, g1 = yy.y > 0.f ? d.y : 0.f, g2 = yy.z > 0.f ? d.z : 0.f,
-                g3 = yy.w > 0.f ? d.w : 0.f;
+    const float4 d = pd[i], zz = pz[i];
+    const float g0 = fmaf(zz.x, fa, fc) > 0.f ? d.x : 0.f, g1 = fmaf(zz.y, fa, fc) > 0.f ? d.y : 0.f,
+                g2 = fmaf(zz.z, fa, fc) > 0.f ? d.z : 0.f, g3 = fmaf(zz.w, fa, fc) > 0.f ? d.w : 0.f;
     s += g0 + g1 + g2 + g3;
     q += g0 * zz.x + g1 * zz.y + g2 * zz.z + g3 * zz.w;
   }
   if (blockIdx.x == 0)
     for (long i = n4 * 4 + threadIdx.x; i < V; i += UT) {
-      const float g = y[plane * V + i] > 0.f ? dy[plane * V + i] : 0.f;
+      const float zv = z[plane * V + i];
+      const float g = fmaf(zv, fa, fc) > 0.f ? dy[plane * V + i] : 0.f;
       s += g;
-      q += g * z[plane * V + i];
+      q += g * zv;
     }
   block_sum2(s, q, sh);
   if (threadIdx.x == 0) {
@@ -178,30 +182,30 @@ __global__ void k_gn_bwd_coef(const double* __restrict__ acc, int B, int C, int 
   }
 }
 
-__global__ __launch_bounds__(UT) void k_gn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
-                                                     const float* __restrict__ z, float* __restrict__ dz,
-                                                     const float* __restrict__ ca, const float* __restrict__ cb,
-                                                     const float* __restrict__ cc, long V) {
+__global__ __launch_bounds__(UT) void k_gn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ z,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float* __restrict__ dz, const float* __restrict__ ca,
+                                                     const float* __restrict__ cb, const float* __restrict__ cc, long V) {
   const long plane = blockIdx.y;
   const float a = ca[plane], b = cb[plane], c = cc[plane];
+  const float fa = scale[plane], fc = shift[plane];
   const float4* pd = (const float4*)(dy + plane * V);
-  const float4* py = (const float4*)(y + plane * V);
   const float4* pz = (const float4*)(z + plane * V);
   float4* po = (float4*)(dz + plane * V);
   const long n4 = V / 4;
   for (long i = (long)blockIdx.x * UT + threadIdx.x; i < n4; i += (long)gridDim.x * UT) {
-    const float4 d = pd[i], yy = py[i], zz = pz[i];
+    const float4 d = pd[i], zz = pz[i];
     float4 o;
-    o.x = fmaf(a, yy.x > 0.f ? d.x : 0.f, fmaf(b, zz.x, c));
-    o.y = fmaf(a, yy.y > 0.f ? d.y : 0.f, fmaf(b, zz.y, c));
-    o.z = fmaf(a, yy.z > 0.f ? d.z : 0.f, fmaf(b, zz.z, c));
-    o.w = fmaf(a, yy.w > 0.f ? d.w : 0.f, fmaf(b, zz.w, c));
+    o.x = fmaf(a, fmaf(zz.x, fa, fc) > 0.f ? d.x : 0.f, fmaf(b, zz.x, c));
+    o.y = fmaf(a, fmaf(zz.y, fa, fc) > 0.f ? d.y : 0.f, fmaf(b, zz.y, c));
+    o.z = fmaf(a, fmaf(zz.z, fa, fc) > 0.f ? d.z : 0.f, fmaf(b, zz.z, c));
+    o.w = fmaf(a, fmaf(zz.w, fa, fc) > 0.f ? d.w : 0.f, fmaf(b, zz.w, c));
     po[i] = o;
   }
   if (blockIdx.x == 0)
     for (long i = n4 * 4 + threadIdx.x; i < V; i += UT) {
       const long j = plane * V + i;
-      dz[j] = fmaf(a, y[j] > 0.f ? dy[j] : 0.f, fmaf(b, z[j], c));
+      dz[j] = fmaf(a, fmaf(z[j], fa, fc) > 0.f ? dy[j] : 0.f, fmaf(b, z[j], c));
     }
 }
 
@@ -519,23 +523,24 @@ using namespace hp;
 
 extern "C" size_t hp_groupnorm_workspace_bytes(int B, int C) { return sizeof(double) * 2 * B * C + sizeof(float) * 3 * B * C; }
 
-// y = relu(GroupNorm(z)); mean/rstd: (B*G) floats saved for backward; workspace: hp_groupnorm_workspace_bytes
-extern "C" int hp_groupnorm_relu_forward(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
-                                         const float* beta, float eps, float* mean, float* rstd, void* workspace,
-                                         void* stream) {
-  HP_REQUIRE(z && y && gamma && beta && mean && rstd && workspace && C % G == 0, "hp_groupnorm_relu_forward: bad argument");
+// y = relu(GroupNorm(z)); mean/rstd: (B*G) floats and scale/shift: (B*C) floats of the affine map, all saved for
+// backward; workspace: hp_groupnorm_workspace_bytes.  chan_stats (optional): per (b, c) {sum, sum of squares} of z as
+// doubles, e.g. from the producing convolution's epilogue (hp_dconv3_forward_fused) -- the statistics pass is skipped.
+extern "C" int hp_groupnorm_relu_forward_v2(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
+                                            const float* beta, float eps, const double* chan_stats, float* mean, float* rstd,
+                                            float* scale, float* shift, void* workspace, void* stream) {
+  HP_REQUIRE(z && y && gamma && beta && mean && rstd && scale && shift && workspace && C % G == 0,
+             "hp_groupnorm_relu_forward: bad argument");
   hipStream_t st = (hipStream_t)stream;
   double* acc = (double*)workspace;
-  float* scale = (float*)(acc + 2 * (long)B * C);
-  float* shift = scale + (long)B * C;
-  HP_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * B * C, st));
   const dim3 grid(chunks_for(V, (long)B * C), (unsigned)(B * C));
-  {
+  if (!chan_stats) {
+    HP_CHECK_HIP(hipMemsetAsync(acc, 0, sizeof(double) * 2 * B * C, st));
     HP_PROF("gn_stats", st);
     hipLaunchKernelGGL(k_plane_stats, grid, dim3(UT), 0, st, z, acc, V);
   }
-  hipLaunchKernelGGL(k_gn_finalize, dim3((B * C + 127) / 128), dim3(128), 0, st, acc, B, C, G, V, eps, gamma, beta, mean, rstd,
-                     scale, shift);
+  hipLaunchKernelGGL(k_gn_finalize, dim3((B * C + 127) / 128), dim3(128), 0, st, chan_stats ? chan_stats : acc, B, C, G, V, eps,
+                     gamma, beta, mean, rstd, scale, shift);
   {
     HP_PROF("gn_apply_relu", st);
     hipLaunchKernelGGL(k_affine_relu, grid, dim3(UT), 0, st, z, y, scale, shift, V);
@@ -544,10 +549,21 @@ extern "C" int hp_groupnorm_relu_forward(const float* z, float* y, int B, int C,
   return HP_OK;
 }
 
-extern "C" int hp_groupnorm_relu_backward(const float* dy, const float* y, const float* z, float* dz, int B, int C, int G,
-                                          long V, const float* gamma, const float* mean, const float* rstd, float* dgamma,
-                                          float* dbeta, void* workspace, void* stream) {
-  HP_REQUIRE(dy && y && z && dz && gamma && mean && rstd && dgamma && dbeta && workspace && C % G == 0,
+extern "C" int hp_groupnorm_relu_forward(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
+                                         const float* beta, float eps, float* mean, float* rstd, void* workspace,
+                                         void* stream) {
+  HP_REQUIRE(workspace, "hp_groupnorm_relu_forward: bad argument");
+  float* scale = (float*)((double*)workspace + 2 * (long)B * C);
+  return hp_groupnorm_relu_forward_v2(z, y, B, C, G, V, gamma, beta, eps, nullptr, mean, rstd, scale, scale + (long)B * C,
+                                      workspace, stream);
+}
+
+// dz, dgamma, dbeta of y = relu(GroupNorm(z)) given dy; scale/shift: the forward's affine map (the ReLU mask is
+// rebuilt from z with it, y is not read)
+extern "C" int hp_groupnorm_relu_backward_v2(const float* dy, const float* z, float* dz, int B, int C, int G, long V,
+                                             const float* gamma, const float* mean, const float* rstd, const float* scale,
+                                             const float* shift, float* dgamma, float* dbeta, void* workspace, void* stream) {
+  HP_REQUIRE(dy && z && dz && gamma && mean && rstd && scale && shift && dgamma && dbeta && workspace && C % G == 0,
              "hp_groupnorm_relu_backward: bad argument");
   hipStream_t st = (hipStream_t)stream;
   double* acc = (double*)workspace;
@@ -558,13 +574,13 @@ extern "C" int hp_groupnorm_relu_backward(const float* dy, const float* y, const
   const dim3 grid(chunks_for(V, (long)B * C), (unsigned)(B * C));
   {
     HP_PROF("gn_bwd_reduce", st);
-    hipLaunchKernelGGL(k_gn_bwd_reduce, grid, dim3(UT), 0, st, dy, y, z, acc, V);
+    hipLaunchKernelGGL(k_gn_bwd_reduce, grid, dim3(UT), 0, st, dy, z, scale, shift, acc, V);
   }
   hipLaunchKernelGGL(k_gn_bwd_coef, dim3((B * C + 127) / 128), dim3(128), 0, st, acc, B, C, G, V, mean, rstd, gamma, dgamma,
                      dbeta, ca, cb, cc);
   {
     HP_PROF("gn_bwd_apply", st);
-    hipLaunchKernelGGL(k_gn_bwd_apply, grid, dim3(UT), 0, st, dy, y, z, dz, ca, cb, cc, V);
+    hipLaunchKernelGGL(k_gn_bwd_apply, grid, dim3(UT), 0, st, dy, z, scale, shift, dz, ca, cb, cc, V);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

@@ -29,8 +29,9 @@ class ResConv3D(nn.Module):
             nn.Identity(), nn.Identity(), nn.Conv3d(basedim, basedim, 3, padding=0, bias=True))
 
     def forward(self, x):
-        h = ops.leaky_add(ops.conv3d_reppad(x, self.tmp[1].weight, self.tmp[1].bias), None, 0.2)
-        return ops.leaky_add(ops.conv3d_reppad(h, self.tmp[4].weight, self.tmp[4].bias), x, 0.2)
+        # both LeakyReLUs and the residual add ride in the convolutions' epilogues
+        h = ops.conv3d_reppad(x, self.tmp[1].weight, self.tmp[1].bias, slope=0.2)
+        return ops.conv3d_reppad(h, self.tmp[4].weight, self.tmp[4].bias, residual=x, slope=0.2)
 
 
 class FeatureExtraction(nn.Module):

@@ -33,56 +33,131 @@ def _stream(t):
     return _lib.current_stream_handle(t.device)
 
 
+def _dconv3_grads(x, w, g, replicate, has_bias, need_dx):
+    """(dx, dw, db) of y = conv3(x, w) + b given g = dL/dy; planar tensors."""
+    L = _lib.lib()
+    b, cin, d, h, wd = x.shape
+    cout = w.shape[0]
+    rp = 1 if replicate else 0
+    st = _stream(x)
+    gx = None
+    if need_dx:
+        gx = torch.empty_like(x)
+        nb = int(L.hp_dconv3_backward_data_workspace_bytes(b, cin, d, h, wd, rp))
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
+        _lib.check(L.hp_dconv3_backward_data(g.data_ptr(), w.data_ptr(), gx.data_ptr(), b, cin, cout, d, h, wd, rp,
+                                             _lib.ptr(ws), st), "hp_dconv3_backward_data")
+    dw = torch.empty_like(w)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+    nbw = int(L.hp_dconv3_backward_weight_workspace_bytes(b, cin, cout, d, h, wd))
+    wsw = torch.empty(nbw // 4, dtype=torch.float32, device=x.device)
+    _lib.check(L.hp_dconv3_backward_weight(x.data_ptr(), g.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
+                                           d, h, wd, rp, wsw.data_ptr(), st), "hp_dconv3_backward_weight")
+    return gx, dw, db
+
+
 class _DConv3(torch.autograd.Function):
-    """y = conv3d(x, w, bias), 3x3x3, stride 1, same size, zero or replicate padding; planar
-    (B,C,D,H,W).  csrc/dconv_kernels.hip."""
+    """y = leaky(conv3d(x, w, bias) [+ res], slope), 3x3x3, stride 1, same size, zero or replicate padding; planar
+    (B,C,D,H,W); slope 1 = no activation.  The residual add and the activation ride in the convolution's epilogue
+    (csrc/dconv_kernels.hip, hp_dconv3_forward_fused)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, replicate):
+    def forward(ctx, x, w, bias, replicate, res=None, slope=1.0):
         _need_cuda(x, "dconv3")
         L = _lib.lib()
         x = x.contiguous()
+        res = res.contiguous() if res is not None else None
         b, cin, d, h, wd = x.shape
         cout = w.shape[0]
         y = torch.empty(b, cout, d, h, wd, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.hp_dconv3_forward(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), y.data_ptr(), b, cin, cout, d, h, wd,
-                                           1 if replicate else 0, _stream(x)), "hp_dconv3_forward")
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (replicate, bias is not None)
+            _lib.check(L.hp_dconv3_forward_fused(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), y.data_ptr(), None,
+                                                 b, cin, cout, d, h, wd, 1 if replicate else 0, float(slope), _stream(x)),
+                       "hp_dconv3_forward_fused")
+        if slope != 1.0:
+            ctx.save_for_backward(x, w, y)
+        else:
+            ctx.save_for_backward(x, w)
+        ctx.cfg = (replicate, bias is not None, res is not None, float(slope))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        L = _lib.lib()
-        x, w = ctx.saved_tensors
-        replicate, has_bias = ctx.cfg
+        replicate, has_bias, has_res, slope = ctx.cfg
         gy = gy.contiguous()
+        if slope != 1.0:
+            x, w, y = ctx.saved_tensors
+            g = torch.empty_like(gy)
+            with torch.cuda.device(gy.device):
+                _lib.check(_lib.lib().hp_leaky_backward(gy.data_ptr(), y.data_ptr(), g.data_ptr(), gy.numel(), slope,
+                                                        _stream(gy)), "hp_leaky_backward")
+        else:
+            x, w = ctx.saved_tensors
+            g = gy
+        with torch.cuda.device(x.device):
+            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0])
+        return gx, dw, db, None, (g if has_res else None), None
+
+
+class _ConvGnRelu(torch.autograd.Function):
+    """y = relu(GroupNorm(conv3d(x, w, bias)))  (DoubleConv half, unet/unet3d.py:14-24) as ONE autograd node: the
+    convolution's epilogue leaves the per-channel sums GroupNorm needs (no statistics pass over z), the backward rebuilds
+    the ReLU mask from z (the normalised tensor is not read back)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, groups, eps):
+        _need_cuda(x, "conv3_gn_relu")
+        L = _lib.lib()
+        x = x.contiguous()
         b, cin, d, h, wd = x.shape
         cout = w.shape[0]
-        rp = 1 if replicate else 0
-        st = _stream(x)
-        gx = None
-        with torch.cuda.device(x.device):
-            if ctx.needs_input_grad[0]:
-                gx = torch.empty_like(x)
-                nb = int(L.hp_dconv3_backward_data_workspace_bytes(b, cin, d, h, wd, rp))
-                ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
-                _lib.check(L.hp_dconv3_backward_data(gy.data_ptr(), w.data_ptr(), gx.data_ptr(), b, cin, cout, d, h, wd, rp,
-                                                     _lib.ptr(ws), st), "hp_dconv3_backward_data")
-            dw = torch.empty_like(w)
-            db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-            nbw = int(L.hp_dconv3_backward_weight_workspace_bytes(b, cin, cout, d, h, wd))
-            wsw = torch.empty(nbw // 4, dtype=torch.float32, device=x.device)
-            _lib.check(L.hp_dconv3_backward_weight(x.data_ptr(), gy.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
-                                                   d, h, wd, rp, wsw.data_ptr(), st), "hp_dconv3_backward_weight")
-        return gx, dw, db, None
+        V = d * h * wd
+        dev = x.device
+        z = torch.empty(b, cout, d, h, wd, dtype=torch.float32, device=dev)
+        y = torch.empty_like(z)
+        stats = torch.empty(2 * b * cout, dtype=torch.float64, device=dev)
+        mean = torch.empty(b * groups, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        aff = torch.empty(2, b * cout, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, cout)) // 4 + 2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            _lib.check(L.hp_dconv3_forward_fused(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), None, z.data_ptr(), stats.data_ptr(),
+                                                 b, cin, cout, d, h, wd, 0, 1.0, st), "hp_dconv3_forward_fused")
+            _lib.check(L.hp_groupnorm_relu_forward_v2(z.data_ptr(), y.data_ptr(), b, cout, groups, V, gamma.data_ptr(),
+                                                      beta.data_ptr(), eps, stats.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                      aff[0].data_ptr(), aff[1].data_ptr(), ws.data_ptr(), st),
+                       "hp_groupnorm_relu_forward_v2")
+        ctx.save_for_backward(x, w, z, gamma, mean, rstd, aff)
+        ctx.cfg = (groups, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w, z, gamma, mean, rstd, aff = ctx.saved_tensors
+        groups, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        b, cout = z.shape[:2]
+        V = z.numel() // (b * cout)
+        dz = torch.empty_like(z)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, cout)) // 4 + 2, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.check(L.hp_groupnorm_relu_backward_v2(dy.data_ptr(), z.data_ptr(), dz.data_ptr(), b, cout, groups, V,
+                                                       gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), aff[0].data_ptr(),
+                                                       aff[1].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                                       _stream(z)), "hp_groupnorm_relu_backward_v2")
+            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0])
+        return gx, dw, db, dgamma, dbeta, None, None
 
 
 # ---------------------------------------------------------------- FeatureExtraction (rows A1, A2)
-def conv3d_reppad(x, w, b, stride=1):
+def conv3d_reppad(x, w, b, stride=1, residual=None, slope=1.0):
+    """ReplicationPad3d(1) + Conv3d(3^3) [+ residual] [+ LeakyReLU(slope)] in one kernel."""
     assert stride == 1, "NlosPose uses FeatureExtraction with stride 1 (models/NlosPose.py:20-24)"
-    return _DConv3.apply(x, w, b, True)
+    return _DConv3.apply(x, w, b, True, residual, slope)
 
 
 class _LeakyAdd(torch.autograd.Function):
@@ -127,7 +202,7 @@ def feature_extraction_fused(x, fe):
     _need_cuda(x, "feature_extraction")
     a = conv3d_reppad(x, fe.conv1[1].weight, fe.conv1[1].bias)
     a = fe.conv1[3](fe.conv1[2](a))
-    return add(a, _DConv3.apply(x, fe.weights, None, False))
+    return _DConv3.apply(x, fe.weights, None, False, a, 1.0)   # box filter branch + learned branch, added in the epilogue
 
 
 # ---------------------------------------------------------------- normalize_feature (row C8)
@@ -168,6 +243,8 @@ def normalize_feature(x):
 
 # ---------------------------------------------------------------- UNet3d (row U1)
 class _GroupNormRelu(torch.autograd.Function):
+    """y = relu(GroupNorm(z)) on its own (the U-Net itself uses _ConvGnRelu)."""
+
     @staticmethod
     def forward(ctx, z, gamma, beta, groups, eps):
         L = _lib.lib()
@@ -177,19 +254,21 @@ class _GroupNormRelu(torch.autograd.Function):
         y = torch.empty_like(z)
         mean = torch.empty(b * groups, dtype=torch.float32, device=z.device)
         rstd = torch.empty_like(mean)
+        aff = torch.empty(2, b * c, dtype=torch.float32, device=z.device)
         ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, c)) // 4 + 2, dtype=torch.float32, device=z.device)
         with torch.cuda.device(z.device):
-            _lib.check(L.hp_groupnorm_relu_forward(z.data_ptr(), y.data_ptr(), b, c, groups, V, gamma.data_ptr(),
-                                                   beta.data_ptr(), eps, mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
-                                                   _stream(z)), "hp_groupnorm_relu_forward")
-        ctx.save_for_backward(z, y, gamma, mean, rstd)
+            _lib.check(L.hp_groupnorm_relu_forward_v2(z.data_ptr(), y.data_ptr(), b, c, groups, V, gamma.data_ptr(),
+                                                      beta.data_ptr(), eps, None, mean.data_ptr(), rstd.data_ptr(),
+                                                      aff[0].data_ptr(), aff[1].data_ptr(), ws.data_ptr(), _stream(z)),
+                       "hp_groupnorm_relu_forward_v2")
+        ctx.save_for_backward(z, gamma, mean, rstd, aff)
         ctx.groups = groups
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        z, y, gamma, mean, rstd = ctx.saved_tensors
+        z, gamma, mean, rstd, aff = ctx.saved_tensors
         dy = dy.contiguous()
         b, c = z.shape[:2]
         V = z.numel() // (b * c)
@@ -198,10 +277,10 @@ class _GroupNormRelu(torch.autograd.Function):
         dbeta = torch.empty_like(gamma)
         ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, c)) // 4 + 2, dtype=torch.float32, device=z.device)
         with torch.cuda.device(z.device):
-            _lib.check(L.hp_groupnorm_relu_backward(dy.data_ptr(), y.data_ptr(), z.data_ptr(), dz.data_ptr(), b, c,
-                                                    ctx.groups, V, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                    dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(z)),
-                       "hp_groupnorm_relu_backward")
+            _lib.check(L.hp_groupnorm_relu_backward_v2(dy.data_ptr(), z.data_ptr(), dz.data_ptr(), b, c, ctx.groups, V,
+                                                       gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), aff[0].data_ptr(),
+                                                       aff[1].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                                       _stream(z)), "hp_groupnorm_relu_backward_v2")
         return dz, dgamma, dbeta, None, None
 
 
@@ -302,7 +381,7 @@ def conv3d(x, w, b=None, stride=1, padding=0):
 
 
 def conv3_gn_relu(x, w, b, gw, gb, groups, eps):
-    return _GroupNormRelu.apply(_DConv3.apply(x, w, b, False), gw, gb, groups, eps)
+    return _ConvGnRelu.apply(x, w, b, gw, gb, groups, eps)
 
 
 def max_pool3d_2(x):

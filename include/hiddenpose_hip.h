@@ -211,6 +211,12 @@ int hp_layout_transpose(const float* in, float* out, int B, long V, int C, int t
  * ---------------------------------------------------------------------- */
 int hp_dconv3_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int D,
                       int H, int W, int replicate_pad, void* stream);
+/* the same convolution with a fused epilogue: y = leaky(conv(x) + bias [+ residual], slope) (slope 1 = none;
+ * ResConv3D, feature_extraction.py:228-256) and, when stats != NULL, per (b, co) {sum y, sum y^2} as doubles
+ * (2*B*cout, zeroed here) for the GroupNorm that follows (unet3d.py:17-18) */
+int hp_dconv3_forward_fused(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                            double* stats, int B, int cin, int cout, int D, int H, int W, int replicate_pad, float slope,
+                            void* stream);
 size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad);
 int hp_dconv3_backward_data(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H, int W,
                             int replicate_pad, void* workspace, void* stream);
@@ -228,9 +234,16 @@ size_t hp_groupnorm_workspace_bytes(int B, int C);
 /* y = relu(GroupNorm_G(z) * gamma + beta)  (unet3d.py:17-18,22-23); mean/rstd: B*G floats kept for backward */
 int hp_groupnorm_relu_forward(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
                               const float* beta, float eps, float* mean, float* rstd, void* workspace, void* stream);
-int hp_groupnorm_relu_backward(const float* dy, const float* y, const float* z, float* dz, int B, int C, int G, long V,
-                               const float* gamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                               void* workspace, void* stream);
+/* the same with (a) scale/shift, B*C floats each: the per-(b,c) affine map y = relu(z*scale + shift), kept for backward;
+ * (b) optional chan_stats: per (b,c) {sum z, sum z^2} as doubles from the producing convolution's epilogue
+ * (hp_dconv3_forward_fused) -- the statistics pass over z is then skipped */
+int hp_groupnorm_relu_forward_v2(const float* z, float* y, int B, int C, int G, long V, const float* gamma,
+                                 const float* beta, float eps, const double* chan_stats, float* mean, float* rstd,
+                                 float* scale, float* shift, void* workspace, void* stream);
+/* backward of the above; the ReLU mask is rebuilt from z with the forward's scale/shift (y is not read) */
+int hp_groupnorm_relu_backward_v2(const float* dy, const float* z, float* dz, int B, int C, int G, long V,
+                                  const float* gamma, const float* mean, const float* rstd, const float* scale,
+                                  const float* shift, float* dgamma, float* dbeta, void* workspace, void* stream);
 /* MaxPool3d(2,2) (unet3d.py:35); planes = B*C */
 int hp_maxpool3d_k2_forward(const float* x, float* y, long planes, int D, int H, int W, void* stream);
 int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* dx, long planes, int D, int H, int W, void* stream);

@@ -3,7 +3,8 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: lctwin ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax   (default: all)
+Sections: lctwin ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax specular e2e128train highres
+(default: all; highres needs ~45 GB of RAM and ~15 minutes)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
 its filler keyed by state_dict name, so tests rebuild identical inputs and
@@ -32,7 +33,7 @@ from hiddenpose_amd import testing as hpt  # noqa: E402
 torch.set_num_threads(8)
 torch.manual_seed(0)
 
-BIN_LEN = {(32, 16): 0.16, (32, 32): 0.16, (128, 128): 0.04, (512, 128): 0.01, (64, 32): 0.08}
+BIN_LEN = {(32, 16): 0.16, (32, 32): 0.16, (128, 128): 0.04, (512, 128): 0.01, (64, 32): 0.08, (1024, 256): 0.005}
 
 
 def save(name, **arrays):
@@ -292,6 +293,190 @@ def sec_softargmax():
     save("softargmax.npz", demo_pred=pred.numpy(), demo_loss=np.float64(loss.item()), rand_pred=rp.numpy())
 
 
+def sec_specular():
+    """material='specular' (models/feature_propagation.py:213-217: g^2 fall-off instead of g^4), forward + input gradient."""
+    import models.feature_propagation as fp
+
+    T, N, B = 32, 16, 2
+    lct = fp.LCT(N, T, BIN_LEN[(T, N)], 2.0, material="specular")
+    x = hpt.synthetic_meas(B, T, N, "uniform", seed=0).requires_grad_(True)
+    y = lct(x, [0] * B, [T] * B)
+    gy = hpt.synthetic_meas(B, T, N, "uniform", seed=100) - 0.5
+    (y * gy).sum().backward()
+    save("lct_specular.npz", y=y.detach().numpy(), gx=x.grad.numpy())
+    print(f"  specular: |y| {y.norm().item():.4g} |gx| {x.grad.norm().item():.4g}")
+
+
+E2E128_PARAMS = ["feature_extraction.weights", "feature_extraction.conv1.1.weight", "feature_extraction.conv1.3.tmp.4.bias",
+                 "autoencoder.conv.double_conv.0.weight", "autoencoder.dec4.conv.double_conv.3.weight", "autoencoder.out.conv.bias",
+                 "pose_net.conv1.weight", "pose_net.bn1.weight", "pose_net.layer1.0.conv2.weight", "pose_net.layer2.0.conv2.weight",
+                 "pose_net.layer3.2.conv1.weight", "pose_net.layer4.1.conv3.weight", "pose_net.head.features.0.weight",
+                 "pose_net.head.features.9.weight", "pose_net.head.features.9.bias"]
+
+
+def sec_e2e128train():
+    """The reference's train step (utils/train_epoch.py:38-76) at its NATIVE shape 128^3, batch 2: losses, joints,
+    sampled heat-maps, 15 named gradients (sampled + L2), post-Adam values and BatchNorm running statistics.  This is
+    the well-conditioned size for gradient parity (at T = N = 32 layer4's BatchNorm normalises over 2 values)."""
+    from models.NlosPose import NlosPose
+    from utils.criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
+
+    T = N = 128
+    B = 2
+    cfg = ref_shims.make_cfg(T, N, BIN_LEN[(T, N)])
+    model = NlosPose(cfg)
+    hpt.fill_module(model)
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410)
+    vol = hpt.synthetic_vol(B, T, N)
+    joints = hpt.synthetic_joints(B, T // 2).reshape(B, -1)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    t0 = time.time()
+    heat, refine = model(meas)
+    jl = L2JointLocationLoss(output_3d=True)(heat, joints, torch.ones_like(joints))
+    vl = BCEDiceLoss()(refine.reshape(B, -1), vol.reshape(B, -1))
+    loss = jl + vl
+    opt.zero_grad()
+    loss.backward()
+    print(f"  e2e128train: fwd+bwd {time.time()-t0:.1f}s  joint loss {jl.item():.6g}  voxel loss {vl.item():.6g}")
+    out = {"joint_loss": np.float64(jl.item()), "voxel_loss": np.float64(vl.item()),
+           "joints": softmax_integral_tensor(heat.detach(), 24, True, 64, 64, 64).numpy(),
+           "heat_l2_per_joint": heat.detach().reshape(B, 24, -1).double().norm(dim=2).numpy(),
+           "heat_sub": heat.detach()[:, :, ::8, ::8, ::8].numpy(), "refine_sub": refine.detach()[:, :, ::8, ::8, ::8].numpy(),
+           "refine_l2": np.float64(refine.detach().double().norm().item())}
+    named = dict(model.named_parameters())
+    for k in E2E128_PARAMS:
+        g = named[k].grad.numpy()
+        out["gl2_" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if g.size > 8192:
+            idx = sample_idx(g.size, 4096, 17)
+            out["gidx_" + k] = idx
+            out["gs_" + k] = g.reshape(-1)[idx]
+        else:
+            out["g_" + k] = g.copy()
+    opt.step()
+    for k in E2E128_PARAMS:
+        v = named[k].detach().numpy()
+        out["adam1_" + k] = v.reshape(-1)[out["gidx_" + k]].copy() if ("gidx_" + k) in out else v.copy()
+    sd = model.state_dict()
+    out["bn1_running_mean"] = sd["pose_net.bn1.running_mean"].numpy()
+    out["bn1_running_var"] = sd["pose_net.bn1.running_var"].numpy()
+    out["l4_bn3_running_var"] = sd["pose_net.layer4.2.bn3.running_var"].numpy()
+    save("e2e_T128_N128_train.npz", **out)
+
+
+def _lean_lct(T, N, bin_len):
+    """Memory-lean restatement of LCT.forward / its adjoint for sizes where the reference's own constructor does not
+    fit this container (its (2N,2N,2M) meshgrids + complex128 spectrum need > 60 GB at 1024 x 256 x 256): the PSF comes
+    from the pinned oracle (bit-exact with the reference's, tests/test_oracle_golden.py), spectra are kept as
+    half-spectra (the padded volume is real and invpsf Hermitian, so R2C/C2R is the same operator).  Checked against
+    the reference's LCT at (T,N) = (64,32) right here before it is used."""
+    import scipy.fft as sfft
+
+    from oracle import nlospose_oracle as O
+
+    slope = (2.0 / 2.0) / (T * bin_len)
+    psf = O.define_psf(N, T, slope)                           # (2T,2N,2N) float32
+    f = sfft.rfftn(psf.astype(np.float64), workers=8)         # complex128 half spectrum
+    del psf
+    inv = np.conjugate(f) / (1 / 1e-1 + f.real ** 2 + f.imag ** 2)
+    del f
+    inv = inv.astype(np.complex64)
+    mtx = torch.from_numpy(O.resampling_operator(T)).to_sparse_csr()
+    mtxi = torch.from_numpy(np.ascontiguousarray(O.resampling_operator(T).T)).to_sparse_csr()
+    g4 = (torch.arange(T, dtype=torch.float32) / (T - 1)).view(T, 1) ** 4
+
+    def run(x, adjoint):                                       # x (T,N,N) float32 tensor
+        v = x.reshape(T, N * N)
+        if not adjoint:
+            v = v * g4
+        v = torch.sparse.mm(mtx, v).reshape(T, N, N).numpy()
+        pad = np.zeros((2 * T, 2 * N, 2 * N), np.float32)
+        pad[:T, :N, :N] = v
+        fr = sfft.rfftn(pad, workers=8)
+        del pad
+        fr *= np.conjugate(inv) if adjoint else inv
+        re = sfft.irfftn(fr, s=(2 * T, 2 * N, 2 * N), workers=8)[:T, :N, :N]
+        del fr
+        o = torch.sparse.mm(mtxi, torch.from_numpy(np.ascontiguousarray(re, dtype=np.float32)).reshape(T, N * N))
+        if adjoint:
+            o = o * g4
+        return o.reshape(T, N, N)
+
+    class Lean(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return torch.stack([run(v, False) for v in x.reshape(-1, T, N, N)]).view_as(x)
+
+        @staticmethod
+        def backward(ctx, gy):
+            return torch.stack([run(v, True) for v in gy.reshape(-1, T, N, N)]).view_as(gy)
+
+    return Lean.apply
+
+
+def sec_highres():
+    """BASELINE configs[3]: 256 x 256 x 1024, FeatureExtraction -> LCT -> normalize_feature -> UNet3d, batch 1,
+    forward and gradients.  FeatureExtraction, normalize_feature and UNet3d are the REFERENCE's modules; the LCT is
+    `_lean_lct` (see there; validated against the reference's LCT below)."""
+    import models.feature_propagation as fp
+    from models.feature_extraction import FeatureExtraction
+    from models.feature_propagation import normalize_feature
+    from unet.unet3d import UNet3d
+
+    # 1. the lean LCT against the reference's own, forward and adjoint, at a size the reference can build
+    Ts, Ns = 64, 32
+    lean = _lean_lct(Ts, Ns, BIN_LEN[(Ts, Ns)])
+    ref = fp.LCT(Ns, Ts, BIN_LEN[(Ts, Ns)], 2.0)
+    xa = hpt.synthetic_meas(1, Ts, Ns, "uniform", seed=3).requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    ga = hpt.synthetic_meas(1, Ts, Ns, "uniform", seed=4) - 0.5
+    ya, yb = ref(xa, [0], [Ts]), lean(xb)
+    (ya * ga).sum().backward()
+    (yb * ga).sum().backward()
+    e1 = ((ya - yb).norm() / ya.norm()).item()
+    e2 = ((xa.grad - xb.grad).norm() / xa.grad.norm()).item()
+    print(f"  lean LCT vs reference LCT at {Ts}x{Ns}x{Ns}: forward rel-L2 {e1:.2e}, adjoint rel-L2 {e2:.2e}")
+    assert e1 < 2e-6 and e2 < 2e-6
+
+    # 2. the full-size pipeline
+    T, N, B = 1024, 256, 1
+    t0 = time.time()
+    lct = _lean_lct(T, N, 5.12 / T)
+    print(f"  highres: lean constants {time.time()-t0:.1f}s")
+    fe = FeatureExtraction(basedim=1, in_channels=1, stride=1)
+    hpt.fill_module(fe, "feature_extraction.")
+    un = UNet3d(in_channels=1, n_channels=4)
+    hpt.fill_module(un, "autoencoder.")
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410).requires_grad_(True)
+    t0 = time.time()
+    a = fe(meas)
+    l = lct(a)
+    f = normalize_feature(l)
+    r = un(f)
+    print(f"  highres: forward {time.time()-t0:.1f}s")
+    # a smooth, seeded cotangent (no 268 MB random tensor to regenerate in the test): loss = mean(r^2) + mean(f)
+    loss = r.square().mean() + f.mean()
+    t0 = time.time()
+    loss.backward()
+    print(f"  highres: backward {time.time()-t0:.1f}s  loss {loss.item():.6g}")
+    out = {"loss": np.float64(loss.item())}
+    idx = sample_idx(T * N * N, 2048, 23)
+    out["idx"] = idx
+    for tag, t in (("fe", a), ("lct", l), ("feature", f), ("refine", r), ("gmeas", meas.grad)):
+        v = t.detach().numpy().reshape(-1)
+        out[tag + "_s"] = v[idx]
+        out[tag + "_l2"] = np.float64(np.sqrt((v.astype(np.float64) ** 2).sum()))
+    for k, p_ in list(fe.named_parameters()):
+        out["g_fe." + k] = p_.grad.numpy().copy()
+    named = dict(un.named_parameters())
+    for k in ["conv.double_conv.0.weight", "conv.double_conv.1.weight", "conv.double_conv.3.weight", "enc2.encoder.1.double_conv.0.weight",
+              "enc4.encoder.1.double_conv.3.weight", "dec1.conv.double_conv.0.weight", "dec4.conv.double_conv.0.weight",
+              "dec4.conv.double_conv.4.bias", "out.conv.weight", "out.conv.bias"]:
+        out["g_un." + k] = named[k].grad.numpy().copy()
+    save("highres_T1024_N256.npz", **out)
+
+
 SFORMER_CFGS = {
     "small": dict(dim=64, num_frames=4, num_joints=24, image_size=32, patch_size=8, channels=1, depth=2, heads=4,
                   dim_head=16, out_dim=128),
@@ -410,7 +595,8 @@ def sec_ingest():
 
 
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
-            "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax}
+            "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
+            "specular": sec_specular, "e2e128train": sec_e2e128train, "highres": sec_highres}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -36,3 +36,49 @@ def test_dconv3(cin, cout, rep, dims):
     assert rel_l2(xg.grad, xd.grad) < 2e-6
     assert rel_l2(wg.grad, wd.grad) < 1e-5
     assert rel_l2(bg.grad, bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,rep,dims", [(1, 1, True, (2, 9, 10, 37)), (1, 1, False, (1, 12, 16, 64)), (4, 4, True, (1, 6, 9, 68))])
+def test_dconv3_fused_residual_leaky(cin, cout, rep, dims):
+    """y = leaky(conv(x) + b + res, 0.2): ResConv3D's second half (feature_extraction.py:228-256) in one kernel."""
+    g = torch.Generator().manual_seed(7 + cin)
+    B, D, H, W = dims
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    r = torch.randn(B, cout, D, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    xd, wd, bd, rd = (t.double().requires_grad_(True) for t in (x, w, b, r))
+    conv = F.conv3d(F.pad(xd, (1,) * 6, mode="replicate"), wd, bd) if rep else F.conv3d(xd, wd, bd, padding=1)
+    ref = F.leaky_relu(conv + rd, 0.2)
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy.double()).sum().backward()
+    xg, wg, bg, rg = (t.cuda().requires_grad_(True) for t in (x, w, b, r))
+    y = ops._DConv3.apply(xg, wg, bg, rep, rg, 0.2)
+    (y * gy.cuda()).sum().backward()
+    assert rel_l2(y, ref) < 2e-6
+    assert rel_l2(xg.grad, xd.grad) < 2e-6 and rel_l2(rg.grad, rd.grad) < 2e-6
+    assert rel_l2(wg.grad, wd.grad) < 1e-5 and rel_l2(bg.grad, bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,dims", [(1, 4, (2, 8, 16, 32)), (4, 4, (1, 20, 9, 66)), (8, 4, (2, 5, 8, 16)), (16, 32, (1, 4, 4, 4)),
+                                           (64, 16, (1, 4, 6, 4)), (4, 8, (1, 37, 8, 8))])
+def test_conv_groupnorm_relu_one_node(cin, cout, dims):
+    """relu(GroupNorm(conv(x))) (DoubleConv half, unet3d.py:14-24) with the statistics taken in the convolution's
+    epilogue and the backward's ReLU mask rebuilt from z."""
+    g = torch.Generator().manual_seed(11 + cin + cout)
+    B, D, H, W = dims
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    xd, wd, bd, gd, btd = (t.double().requires_grad_(True) for t in (x, w, b, gamma, beta))
+    ref = F.relu(F.group_norm(F.conv3d(xd, wd, bd, padding=1), 4, gd, btd, 1e-5))
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy.double()).sum().backward()
+    xg, wg, bg, gg, btg = (t.cuda().requires_grad_(True) for t in (x, w, b, gamma, beta))
+    y = ops.conv3_gn_relu(xg, wg, bg, gg, btg, 4, 1e-5)
+    (y * gy.cuda()).sum().backward()
+    assert rel_l2(y, ref) < 3e-6
+    assert rel_l2(xg.grad, xd.grad) < 2e-5
+    assert rel_l2(wg.grad, wd.grad) < 2e-5 and rel_l2(bg.grad, bd.grad) < 2e-5
+    assert rel_l2(gg.grad, gd.grad) < 2e-5 and rel_l2(btg.grad, btd.grad) < 2e-5

@@ -99,6 +99,19 @@ def test_full_size_vs_golden_samples(T, N, bin_len, golden):
     assert rel_l2(y2.cpu().numpy(), 2 * y.detach().cpu().numpy()) < 1e-6
 
 
+def test_specular_material_vs_reference_golden(golden):
+    """material='specular' (g^2 fall-off, models/feature_propagation.py:213-217), forward and adjoint."""
+    g = golden("lct_specular.npz")
+    lct = LCT(16, 32, 0.16, 2.0, material="specular")
+    x = hpt.synthetic_meas(2, 32, 16, "uniform", seed=0).cuda().requires_grad_(True)
+    y = lct(x, [0, 0], [32, 32])
+    gy = (hpt.synthetic_meas(2, 32, 16, "uniform", seed=100) - 0.5).cuda()
+    (y * gy).sum().backward()
+    assert rel_l2(y.detach().cpu().numpy(), g["y"]) < 1e-5
+    assert rel_l2(x.grad.cpu().numpy(), g["gx"]) < 1e-5
+    assert rel_l2(y.detach().cpu().numpy(), golden("lct_io.npz")["small_y"]) > 1e-2
+
+
 def test_time_windows_vs_reference_golden(golden):
     """LCT.forward(x, tbes, tens) with partial windows (models/feature_propagation.py:193-200), forward and the
     gradient that flows back into the window."""

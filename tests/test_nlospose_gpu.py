@@ -222,3 +222,87 @@ def test_train_forward_odd_batches_vs_oracle(B):
     if B > 1:  # train-mode BatchNorm over a batch of one 1x1x1 map at layer4 is degenerate in the reference as well
         assert rel_l2(heat, ref_heat.detach().numpy()) < TOL
         assert abs(loss.item() / ref_loss.item() - 1) < TOL
+
+
+def test_train_step_native_128_batch2_vs_reference_golden(golden, capsys):
+    """The reference's train step at its native shape (128^3, batch 2; tests/golden/make_goldens.py e2e128train):
+    losses, decoded joints, heat-maps, 15 named gradients, the Adam step and BatchNorm running statistics.  At this
+    size every BatchNorm normalises over >= 1024 values, so gradients are held to 1e-3 (the T = 32 golden needs
+    3e-2 because layer4 normalises over 2 values per channel there)."""
+    g = golden("e2e_T128_N128_train.npz")
+    B, T, N = 2, 128, 128
+    cfg, model = make_model(T, N)
+    model.train()
+    meas = hpt.synthetic_meas(B, T, N).cuda()
+    vol = hpt.synthetic_vol(B, T, N).cuda()
+    joints = hpt.synthetic_joints(B, T // 2).cuda()
+    criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+    loss, jl, vl, heat, refine = compute_loss(model, criterion, voxel_criterion, meas, vol, joints)
+    optimizer.zero_grad()
+    loss.backward()
+    assert abs(jl.item() / float(g["joint_loss"]) - 1) < TOL
+    assert abs(vl.item() / float(g["voxel_loss"]) - 1) < TOL
+    tj = softmax_integral_tensor(heat.detach(), 24, True, 64, 64, 64)
+    assert hpt.mpjpe(tj.cpu(), torch.from_numpy(g["joints"])) < TOL * 64
+    l2 = heat.detach().reshape(B, 24, -1).double().norm(dim=2).cpu().numpy()
+    assert np.abs(l2 / g["heat_l2_per_joint"] - 1).max() < TOL
+    assert rel_l2(heat.detach()[:, :, ::8, ::8, ::8], g["heat_sub"]) < TOL
+    assert rel_l2(refine.detach()[:, :, ::8, ::8, ::8], g["refine_sub"]) < TOL
+    named = dict(model.named_parameters())
+    keys = [k[4:] for k in g.files if k.startswith("gl2_")]
+    assert len(keys) == 15
+    worst = {}
+    for k in keys:
+        gr = named[k].grad.detach()
+        e_l2 = abs(gr.double().norm().item() / float(g["gl2_" + k]) - 1)
+        if "gidx_" + k in g.files:
+            e = rel_l2(gr.reshape(-1)[torch.from_numpy(g["gidx_" + k]).cuda()], g["gs_" + k])
+        else:
+            e = rel_l2(gr, g["g_" + k])
+        worst[k] = max(e, e_l2)
+    with capsys.disabled():
+        print("\n[128^3 B=2 train step vs reference] gradient rel-L2: " + ", ".join(f"{k.split('.', 1)[1]} {v:.1e}" for k, v in worst.items()))
+    for k, v in worst.items():
+        assert v < TOL, (k, v)
+    optimizer.step()
+    for k in keys:
+        v = named[k].detach()
+        ref = g["adam1_" + k]
+        got = v.reshape(-1)[torch.from_numpy(g["gidx_" + k]).cuda()] if "gidx_" + k in g.files else v
+        # first Adam step moves every weight by lr * g / (|g| + eps): entries with |g| ~ eps may differ by up to lr
+        assert float((got.cpu().reshape(-1) - torch.from_numpy(ref).reshape(-1)).abs().max()) < 2.1e-3, k
+        assert rel_l2(got, ref) < TOL, k
+    sd = model.state_dict()
+    assert rel_l2(sd["pose_net.bn1.running_mean"], g["bn1_running_mean"]) < TOL
+    assert rel_l2(sd["pose_net.bn1.running_var"], g["bn1_running_var"]) < TOL
+    assert rel_l2(sd["pose_net.layer4.2.bn3.running_var"], g["l4_bn3_running_var"]) < TOL
+
+
+def test_train_step_batch4_vs_oracle():
+    """The headline batch size (4 per GPU; the reference itself stops at 3) through the whole model in train mode at
+    T = N = 32: heat-maps, refined volume, both losses and gradients against the oracle's autograd."""
+    from oracle import nlospose_oracle as O
+
+    T = N = 32
+    B = 4
+    cfg, model = make_model(T, N)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.train()
+    meas = hpt.synthetic_meas(B, T, N, seed=60)
+    vol = hpt.synthetic_vol(B, T, N, seed=61)
+    joints = hpt.synthetic_joints(B, T // 2, seed=62)
+    criterion, voxel_criterion, _, _ = build_training(cfg, model)
+    loss, jl, vl, heat, refine = compute_loss(model, criterion, voxel_criterion, meas.cuda(), vol.cuda(), joints.cuda())
+    loss.backward()
+    keys = ["feature_extraction.weights", "autoencoder.conv.double_conv.0.weight", "autoencoder.out.conv.bias",
+            "pose_net.conv1.weight", "pose_net.layer1.0.conv2.weight", "pose_net.head.features.9.bias"]
+    sdg = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+    k = O.LCTConstants(N, T, cfg.MODEL.BIN_LEN)
+    ref_loss, ref_jl, ref_vl, ref_heat, ref_refine = O.train_loss(meas, vol, joints.reshape(B, -1), sdg, k)
+    ref_loss.backward()
+    assert rel_l2(refine, ref_refine.detach().numpy()) < TOL
+    assert rel_l2(heat, ref_heat.detach().numpy()) < TOL
+    assert abs(jl.item() / ref_jl.item() - 1) < TOL and abs(vl.item() / ref_vl.item() - 1) < TOL
+    named = dict(model.named_parameters())
+    for kk in keys:
+        assert rel_l2(named[kk].grad, sdg[kk].grad) < 3e-2, kk   # T = 32: layer4 BatchNorm over 4 values per channel
