@@ -390,8 +390,11 @@ template <int PADMODE>
 __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int cin,
                                                          int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad,
-                                                         long wsco, long wsci, int flip, int tiles_x, int tiles_y, int zchunk) {
+                                                         long wsco, long wsci, int flip, int tiles_x, int tiles_y, int zchunk,
+                                                         const float* __restrict__ res, double* __restrict__ stats, float slope) {
   __shared__ float ring[4 * WG_PLANE];
+  __shared__ float sred[4][8];
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
   __shared__ __attribute__((aligned(16))) float wl[4 * 4 * 28];  // [ci][co][28]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3;
@@ -509,14 +512,45 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
           for (int i = 0; i < 4; ++i) {
             const int oc = cog * 4 + i;
             if (oc < cout) {
-              float* yp = y + ((long)b * cout + oc) * ocs + ((long)z * Ho + oy) * Wo + ox;
-              *yp = acc[r][i] + (c0 == 0 ? (bias ? bias[oc] : 0.f) : *yp);
+              const long o = ((long)b * cout + oc) * ocs + ((long)z * Ho + oy) * Wo + ox;
+              float v = acc[r][i] + (c0 == 0 ? (bias ? bias[oc] : 0.f) : y[o]);
+              if (c0 + 4 >= cin) {  // last channel chunk: the sum is complete -> residual, activation, statistics
+                if (res) v += res[o];
+                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
+                st1[i] += v;
+                st2[i] += v * v;
+              }
+              y[o] = v;
             }
           }
         }
       }
       if (z + 1 < ze) stage_store(z - pad + 3, nxt);  // the slot held plane z - pad - 1, last read one barrier ago
       __syncthreads();
+    }
+  }
+  if (stats) {
+    // per output channel of this group: all 64 lanes of the four waves hold partial sums
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = st1[i], q = st2[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+      }
+      if (lane == 0) {
+        sred[wave][i] = a;
+        sred[wave][4 + i] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 8) {
+      const int co = cog * 4 + (tid & 3);
+      if (co < cout) {
+        const float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+        atomicAdd(stats + ((long)b * cout + co) * 2 + (tid >> 2), (double)v);
+      }
     }
   }
 }
@@ -759,9 +793,12 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_f16(const float* __restrict__
 }
 
 // generic entry: y (B,cout,Do,Ho,Wo) = conv3(x (B,cin,Di,Hi,Wi)) with weight(co,ci,tap) = w[co*wsco + ci*wsci + tap']
-static bool use_old_dconv() {
+// The 16x16x4 kernel is numerically identical but measured 1.5x SLOWER than the 4x4x1 kernel at 256x256x1024 (its
+// 12-of-16-column MFMA peaks at 3/4 of the matrix rate and the matrix pipe stays ~40 % busy in both), so it is
+// opt-in (HP_DCONV_16X16=1) until its issue pattern is understood.
+static bool use_f16_dconv() {
   static const bool v = [] {
-    const char* e = getenv("HP_DCONV_4X4");
+    const char* e = getenv("HP_DCONV_16X16");
     return e && atoi(e) != 0;
   }();
   return v;
@@ -776,18 +813,18 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
   const int zchunk = (Do + zsplit - 1) / zsplit;
   zsplit = (Do + zchunk - 1) / zchunk;
   dim3 grid((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)B, (unsigned)cog_n);
-  if (use_old_dconv() && !res && !stats && slope == 1.0f) {
+  if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * cout, st));
+  if (!use_f16_dconv()) {
     if (padmode)
       hipLaunchKernelGGL((k_dconv3_mfma<1>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
-                         wsci, flip, tiles_x, tiles_y, zchunk);
+                         wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope);
     else
       hipLaunchKernelGGL((k_dconv3_mfma<0>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
-                         wsci, flip, tiles_x, tiles_y, zchunk);
+                         wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
   static_assert(F_TY == WG_TY && F_TX == WG_TX, "both kernels share the workgroup tiling");
-  if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * cout, st));
   for (int c_base = 0; c_base < cin; c_base += F_MAXC) {
     const int here = std::min(F_MAXC, cin - c_base);
     const bool last = c_base + here >= cin;

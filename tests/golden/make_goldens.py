@@ -362,6 +362,35 @@ def sec_e2e128train():
     out["bn1_running_mean"] = sd["pose_net.bn1.running_mean"].numpy()
     out["bn1_running_var"] = sd["pose_net.bn1.running_var"].numpy()
     out["l4_bn3_running_var"] = sd["pose_net.layer4.2.bn3.running_var"].numpy()
+
+    # Conditioning of this step: the SAME reference step in float64.  |g32 - g64| / |g64| per parameter is what fp32
+    # rounding alone does to each gradient in the reference itself (ReLU masks and batch statistics re-decided per
+    # layer amplify last-bit differences); a kernel cannot be held to a tighter bar than the reference holds itself.
+    del heat, refine, loss, opt
+    model64 = NlosPose(cfg)
+    hpt.fill_module(model64)
+    model64 = model64.double().train()
+    lctm = model64.feature_propagation.method
+    for a in ("gridz_1xMx1x1_todev", "mtx_MxM_todev", "mtxi_MxM_todev", "invpsf_real_todev", "invpsf_imag_todev", "datapad_Dx2Tx2Hx2W"):
+        setattr(lctm, a, getattr(lctm, a).double())
+    t0 = time.time()
+    h64, r64 = model64(meas.double())
+    l64 = (L2JointLocationLoss(output_3d=True)(h64, joints.double(), torch.ones_like(joints).double())
+           + BCEDiceLoss()(r64.reshape(B, -1), vol.double().reshape(B, -1)))
+    l64.backward()
+    print(f"  e2e128train float64: fwd+bwd {time.time()-t0:.1f}s  loss {l64.item():.9g}")
+    named64 = dict(model64.named_parameters())
+    for k in E2E128_PARAMS:
+        g64 = named64[k].grad.numpy()
+        g32 = named[k].grad.numpy().astype(np.float64)
+        out["spread_" + k] = np.float64(np.linalg.norm(g32 - g64) / max(np.linalg.norm(g64), 1e-300))
+        out["g64l2_" + k] = np.float64(np.linalg.norm(g64))
+        if ("gidx_" + k) in out:
+            out["gs64_" + k] = g64.reshape(-1)[out["gidx_" + k]]
+        else:
+            out["g64_" + k] = g64.copy()
+    out["loss64"] = np.float64(l64.item())
+    print("  fp32-vs-fp64 gradient spread of the reference: " + ", ".join(f"{k.split('.', 1)[1]} {float(out['spread_' + k]):.1e}" for k in E2E128_PARAMS))
     save("e2e_T128_N128_train.npz", **out)
 
 
