@@ -18,26 +18,23 @@
 namespace hp {
 
 
-// adjoint of replicate padding by 1: dx[p] = sum of the halo-domain cells that clamp to p
-__global__ void k_fold_replicate(const float* __restrict__ dpad, float* __restrict__ dx, long nvol, int D, int H, int W) {
-  const int De = D + 2, He = H + 2, We = W + 2;
-  const long per = (long)D * H * W, total = nvol * per;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long vol = i / per;
-    long r = i - vol * per;
-    const int z = (int)(r / ((long)H * W));
-    r -= (long)z * H * W;
-    const int yy = (int)(r / W), xx = (int)(r - (long)yy * W);
-    const int z0 = z == 0 ? 0 : z + 1, z1 = z == D - 1 ? D + 1 : z + 1;
-    const int y0 = yy == 0 ? 0 : yy + 1, y1 = yy == H - 1 ? H + 1 : yy + 1;
-    const int x0 = xx == 0 ? 0 : xx + 1, x1 = xx == W - 1 ? W + 1 : xx + 1;
-    float s = 0.f;
-    const float* p = dpad + vol * (long)De * He * We;
-    for (int a = z0; a <= z1; ++a)
-      for (int bb = y0; bb <= y1; ++bb)
-        for (int c = x0; c <= x1; ++c) s += p[((long)a * He + bb) * We + c];
-    dx[i] = s;
-  }
+// adjoint of replicate padding by 1: dx[p] = sum of the halo-domain cells that clamp to p.  grid (x tiles, H, nvol * D):
+// no index divisions, interior cells are one coalesced read; only the six faces sum 2 / 4 / 8 cells.
+__global__ __launch_bounds__(256) void k_fold_replicate(const float* __restrict__ dpad, float* __restrict__ dx, int D, int H, int W) {
+  const int xx = blockIdx.x * 256 + threadIdx.x;
+  if (xx >= W) return;
+  const int yy = blockIdx.y, z = blockIdx.z % D;
+  const long vol = blockIdx.z / D;
+  const int He = H + 2, We = W + 2;
+  const int z0 = z == 0 ? 0 : z + 1, z1 = z == D - 1 ? D + 1 : z + 1;
+  const int y0 = yy == 0 ? 0 : yy + 1, y1 = yy == H - 1 ? H + 1 : yy + 1;
+  const int x0 = xx == 0 ? 0 : xx + 1, x1 = xx == W - 1 ? W + 1 : xx + 1;
+  const float* p = dpad + vol * (long)(D + 2) * He * We;
+  float s = 0.f;
+  for (int a = z0; a <= z1; ++a)
+    for (int bb = y0; bb <= y1; ++bb)
+      for (int c = x0; c <= x1; ++c) s += p[((long)a * He + bb) * We + c];
+  dx[((vol * D + z) * H + yy) * (long)W + xx] = s;
 }
 
 // Weight gradient on the matrix cores, for any channel count: v_mfma_f32_4x4x1_16b_f32 computes 16 independent
@@ -138,23 +135,20 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   __syncthreads();
   // this lane's offset inside a plane for row r, run q: (sub * PY + (2*wave + r) + dy) * PX + q*16 + blk + dx
   const int lbase = (sub * WG_PY + 2 * wave) * WG_PX + blk;
-  for (int z = zb; z < ze; ++z) {
-    float nxt[SK];
-    if (z + 1 < ze) stage_load(z + 2, nxt);
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
+  // g of one plane: 8 (row, run) values per lane
+  auto g_load = [&](int z, float (&gv)[8]) {
+#pragma unroll
+    for (int rq = 0; rq < 8; ++rq) {
+      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
+      gv[rq] = (co_ok && z < ze && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
+    }
+  };
+  auto multiply = [&](int z, const float (&gv)[8]) {
     const float* p0 = ring + ((z - 1) & 3) * WG_PLANE + lbase;
     const float* p1 = ring + (z & 3) * WG_PLANE + lbase;
     const float* p2 = ring + ((z + 1) & 3) * WG_PLANE + lbase;
-    // 8 (row, run) pairs per plane, one g value each; the next pair's g is in flight while this one multiplies
-    auto g_at = [&](int rq) -> float {
-      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
-      return (co_ok && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
-    };
-    float gnext = g_at(0);
-#pragma unroll 1
+#pragma unroll
     for (int rq = 0; rq < 8; ++rq) {
-      const float gv = gnext;
-      if (rq + 1 < 8) gnext = g_at(rq + 1);
       const int off = (rq >> 2) * WG_PX + (rq & 3) * 16;
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz) {
@@ -164,12 +158,33 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx)
             acc[(dz * 3 + dy) * 3 + dx] =
-                __builtin_amdgcn_mfma_f32_4x4x1f32(gv, pl[dy * WG_PX + dx], acc[(dz * 3 + dy) * 3 + dx], 0, 0, 0);
+                __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], pl[dy * WG_PX + dx], acc[(dz * 3 + dy) * 3 + dx], 0, 0, 0);
       }
-      if (want_db) acc[27] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, 1.0f, acc[27], 0, 0, 0);
+      if (want_db) acc[27] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], 1.0f, acc[27], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // one (row, run) at a time: the unrolled body must not hoist all 216 LDS reads
     }
-    if (z + 1 < ze) stage_store(z + 2, nxt);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
+  };
+  // Everything a plane needs from global memory is requested one full step (g) or two steps (x planes) before it is
+  // used: with single-step prefetch and g fetched inside its own step the kernel was bound by the few KB it kept in
+  // flight per CU, not by the matrix pipe.
+  float nA[SK], nB[SK], gA[8], gB[8];
+  if (zb < ze) g_load(zb, gA);
+  if (zb + 1 < ze) stage_load(zb + 2, nA);
+  for (int z = zb; z < ze; z += 2) {
+    if (z + 2 < ze) stage_load(z + 3, nB);
+    g_load(z + 1, gB);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+    multiply(z, gA);
+    if (z + 1 < ze) stage_store(z + 2, nA);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
     __syncthreads();
+    if (z + 1 < ze) {
+      if (z + 3 < ze) stage_load(z + 4, nA);
+      g_load(z + 2, gA);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(z + 1, gB);
+      if (z + 2 < ze) stage_store(z + 3, nB);
+      __syncthreads();
+    }
   }
   // sum the 16 blocks: lanes with equal (lane & 3) hold the same (., j) column of different voxels
 #pragma unroll
@@ -285,33 +300,48 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   }
   __syncthreads();
   const int lbase = (2 * wave) * WG_PX + blk;
-  for (int z = zb; z < ze; ++z) {
-    float nxt[SK];
-    if (z + 1 < ze) stage_load(z + 2, nxt);
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
+  auto g_load = [&](int z, float (&gv)[8]) {
+#pragma unroll
+    for (int rq = 0; rq < 8; ++rq) {
+      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
+      gv[rq] = (co_ok && z < ze && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
+    }
+  };
+  auto multiply = [&](int z, const float (&gv)[8]) {
     const float* pm[7];
 #pragma unroll
     for (int m = 0; m < 7; ++m) pm[m] = ring + ((z - 1 + tdz[m]) & 3) * W1_PLANE + lbase + toff[m];
-    auto g_at = [&](int rq) -> float {
-      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
-      return (co_ok && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
-    };
-    float gnext = g_at(0);
-#pragma unroll 1
+#pragma unroll
     for (int rq = 0; rq < 8; ++rq) {
-      const float gv = gnext;
-      if (rq + 1 < 8) gnext = g_at(rq + 1);
       const int off = (rq >> 2) * WG_PX + (rq & 3) * 16;
 #pragma unroll
       for (int m = 0; m < 7; ++m) {
         float xv = pm[m][off];
         if (m == 6) xv = last_ok ? xv : 0.f;
-        acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, xv, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], xv, acc[m], 0, 0, 0);
       }
-      acc[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, 1.0f, acc[7], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], 1.0f, acc[7], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (z + 1 < ze) stage_store(z + 2, nxt);
+  };
+  float nA[SK], nB[SK], gA[8], gB[8];  // see k_dconv3_wgrad_mfma: g one step ahead, x planes two steps ahead
+  if (zb < ze) g_load(zb, gA);
+  if (zb + 1 < ze) stage_load(zb + 2, nA);
+  for (int z = zb; z < ze; z += 2) {
+    if (z + 2 < ze) stage_load(z + 3, nB);
+    g_load(z + 1, gB);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(z, gA);
+    if (z + 1 < ze) stage_store(z + 2, nA);
     __syncthreads();
+    if (z + 1 < ze) {
+      if (z + 3 < ze) stage_load(z + 4, nA);
+      g_load(z + 2, gA);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(z + 1, gB);
+      if (z + 2 < ze) stage_store(z + 3, nB);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int m = 0; m < 8; ++m)
@@ -469,13 +499,12 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     }
     __syncthreads();
     const int lbase = (2 * wave) * WG_PX + lane;
-    for (int z = zb; z < ze; ++z) {
-      float nxt[SK];
-      if (z + 1 < ze) stage_load(z - pad + 3, nxt);
-      __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
+    // one output plane: multiply against the three ring planes, store
+    auto compute = [&](int z) {
       const float* p0 = ring + ((z - pad) & 3) * WG_PLANE + lbase;
       const float* p1 = ring + ((z - pad + 1) & 3) * WG_PLANE + lbase;
       const float* p2 = ring + ((z - pad + 2) & 3) * WG_PLANE + lbase;
+      // (six accumulation chains -- row x dz -- instead of two were measured: 20 % slower)
       f32x4 acc[2];
       acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -525,8 +554,24 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
           }
         }
       }
-      if (z + 1 < ze) stage_store(z - pad + 3, nxt);  // the slot held plane z - pad - 1, last read one barrier ago
+    };
+    // Two planes are in flight at any time (register sets A / B): with a single plane the kernel was bound by the bytes it
+    // kept outstanding (~22 KB per CU against a ~2 us loaded memory latency), not by the matrix pipe or LDS.
+    float nA[SK], nB[SK];
+    if (zb + 1 < ze) stage_load(zb - pad + 3, nA);
+    for (int z = zb; z < ze; z += 2) {
+      if (z + 2 < ze) stage_load(z - pad + 4, nB);
+      __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
+      compute(z);
+      if (z + 1 < ze) stage_store(z - pad + 3, nA);  // the slot held plane z - pad - 1, last read one barrier ago
       __syncthreads();
+      if (z + 1 < ze) {
+        if (z + 3 < ze) stage_load(z - pad + 5, nA);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(z + 1);
+        if (z + 2 < ze) stage_store(z - pad + 4, nB);
+        __syncthreads();
+      }
     }
   }
   if (stats) {
@@ -792,10 +837,155 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_f16(const float* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Single-channel 3x3x3 stencil (FeatureExtraction: six 1 -> 1 convolutions per pass, forward and data gradient).
+// 54 FLOP per 8 bytes is far below the machine balance, and on the matrix-core kernels above a 1 -> 1 layer pays the
+// whole per-plane staging / epilogue overhead for a quarter of the MFMAs (0.8 ms per layer at 256 x 256 x 1024 against
+// 0.11 ms of HBM time).  Here a thread owns four consecutive x outputs of one row and slides along z with the
+// 3 planes x 3 rows x 6 columns it needs in registers: one new plane = 18 loads (served by L1/L2: neighbouring
+// threads share all but their own four columns) for 108 FMAs; weights are wave-uniform scalars.  Same generic
+// interface as run_dconv (pad 1 forward, pad 2 for the replicate-padding gradient on the halo domain, flipped taps).
+template <int PADMODE>
+__global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                    float* __restrict__ y, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                                    int pad, int flip, int zchunk, float slope) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ox = (blockIdx.x * 64 + tx) * 4, oy = blockIdx.y * 4 + ty;
+  const int nzc = (Do + zchunk - 1) / zchunk;
+  const int b = blockIdx.z / nzc, zb = (blockIdx.z % nzc) * zchunk, ze = min(Do, zb + zchunk);
+  if (oy >= Ho) return;  // a wave is one row: it leaves as a whole (lanes past Wo stay: they feed their neighbours)
+  const bool live = ox < Wo;
+  float wt[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) wt[t] = w[flip ? 26 - t : t];
+  const float bv = bias ? bias[0] : 0.f;
+  const float* xb = x + (long)b * Di * Hi * Wi;
+  // row / column addressing of the 3 x 6 window, fixed for the whole walk
+  int roff[3], coff[6];
+  bool rok[3], cok[6];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    int yy = oy - pad + r;
+    rok[r] = PADMODE == 1 || (unsigned)yy < (unsigned)Hi;
+    yy = min(max(yy, 0), Hi - 1);
+    roff[r] = yy * Wi;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    int xx = ox - pad + c;
+    cok[c] = PADMODE == 1 || (unsigned)xx < (unsigned)Wi;
+    coff[c] = min(max(xx, 0), Wi - 1);
+  }
+  // Rows whose length is a multiple of 4: one aligned 16-byte load per row and lane (columns ox .. ox+3); the two
+  // window columns outside it come from the neighbouring lanes (whole-wave DPP shifts), only lanes 0 / 63 load them.
+  const bool vload = (Wi & 3) == 0 && (pad == 1 || pad == 2);
+  const bool own_ok = ox + 3 < Wi;
+  auto load_plane = [&](int zin, float (&v)[3][6]) {
+    bool zok = PADMODE == 1 || (unsigned)zin < (unsigned)Di;
+    const float* src = xb + (long)min(max(zin, 0), Di - 1) * Hi * Wi;
+    if (vload) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const bool ok = zok && rok[r];
+        const float4 own = (ok && own_ok) ? *reinterpret_cast<const float4*>(src + roff[r] + ox) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float lz = dpp_mov<0x138>(own.z), lw = dpp_mov<0x138>(own.w);  // wave_shr:1 -> lane i reads lane i-1
+        float rx = dpp_mov<0x130>(own.x);                               // wave_shl:1 -> lane i reads lane i+1
+        if (tx == 0) {
+          lw = (ok && (PADMODE == 1 || ox >= 1)) ? src[roff[r] + max(ox - 1, 0)] : 0.f;
+          lz = (ok && (PADMODE == 1 || ox >= 2)) ? src[roff[r] + max(ox - 2, 0)] : 0.f;
+        }
+        if (tx == 63 || ox + 4 >= Wi) rx = (ok && (PADMODE == 1 || ox + 4 < Wi)) ? src[roff[r] + min(ox + 4, Wi - 1)] : 0.f;
+        if (pad == 1) {
+          v[r][0] = lw; v[r][1] = own.x; v[r][2] = own.y; v[r][3] = own.z; v[r][4] = own.w; v[r][5] = rx;
+        } else {
+          v[r][0] = lz; v[r][1] = lw; v[r][2] = own.x; v[r][3] = own.y; v[r][4] = own.z; v[r][5] = own.w;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[r][c] = (zok && rok[r] && cok[c]) ? src[roff[r] + coff[c]] : 0.f;
+  };
+  const bool vec = (Wo & 3) == 0;
+  auto emit = [&](int z, const float (&p0)[3][6], const float (&p1)[3][6], const float (&p2)[3][6]) {
+    float o[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = fmaf(wt[dy * 3 + dx], p0[dy][i + dx], o[i]);
+          o[i] = fmaf(wt[9 + dy * 3 + dx], p1[dy][i + dx], o[i]);
+          o[i] = fmaf(wt[18 + dy * 3 + dx], p2[dy][i + dx], o[i]);
+        }
+    const long ob = (((long)b * Do + z) * Ho + oy) * Wo + ox;
+    if (!live) return;
+    if (vec) {
+      float4 r4 = make_float4(o[0], o[1], o[2], o[3]);
+      if (res) {
+        const float4 rv = *reinterpret_cast<const float4*>(res + ob);
+        r4.x += rv.x; r4.y += rv.y; r4.z += rv.z; r4.w += rv.w;
+      }
+      if (slope != 1.0f) {
+        r4.x = r4.x > 0.f ? r4.x : r4.x * slope; r4.y = r4.y > 0.f ? r4.y : r4.y * slope;
+        r4.z = r4.z > 0.f ? r4.z : r4.z * slope; r4.w = r4.w > 0.f ? r4.w : r4.w * slope;
+      }
+      *reinterpret_cast<float4*>(y + ob) = r4;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ox + i < Wo) {
+          float r = o[i] + (res ? res[ob + i] : 0.f);
+          if (slope != 1.0f) r = r > 0.f ? r : r * slope;
+          y[ob + i] = r;
+        }
+    }
+  };
+  // Five plane buffers in rotation: three under the stencil, two in flight.  With the next plane requested only when the
+  // current one was done, a wave kept 3 KB outstanding and the kernel ran at the memory LATENCY (1.7 TB/s).
+  float p0[3][6], p1[3][6], p2[3][6], p3[3][6], p4[3][6];
+  load_plane(zb - pad, p0);
+  load_plane(zb - pad + 1, p1);
+  load_plane(zb - pad + 2, p2);
+  load_plane(zb - pad + 3, p3);
+  for (int z = zb; z < ze; z += 5) {
+    load_plane(z - pad + 4, p4);
+    emit(z, p0, p1, p2);
+    if (z + 1 < ze) {
+      load_plane(z - pad + 5, p0);
+      emit(z + 1, p1, p2, p3);
+    }
+    if (z + 2 < ze) {
+      load_plane(z - pad + 6, p1);
+      emit(z + 2, p2, p3, p4);
+    }
+    if (z + 3 < ze) {
+      load_plane(z - pad + 7, p2);
+      emit(z + 3, p3, p4, p0);
+    }
+    if (z + 4 < ze) {
+      load_plane(z - pad + 8, p3);
+      emit(z + 4, p4, p0, p1);
+    }
+  }
+}
+
 // generic entry: y (B,cout,Do,Ho,Wo) = conv3(x (B,cin,Di,Hi,Wi)) with weight(co,ci,tap) = w[co*wsco + ci*wsci + tap']
 // The 16x16x4 kernel is numerically identical but measured 1.5x SLOWER than the 4x4x1 kernel at 256x256x1024 (its
 // 12-of-16-column MFMA peaks at 3/4 of the matrix rate and the matrix pipe stays ~40 % busy in both), so it is
 // opt-in (HP_DCONV_16X16=1) until its issue pattern is understood.
+static bool use_mfma_c1() {  // A/B switch: single-channel layers on the matrix-core kernel instead of the stencil kernel
+  static const bool v = [] {
+    const char* e = getenv("HP_DCONV_C1_MFMA");
+    return e && atoi(e) != 0;
+  }();
+  return v;
+}
 static bool use_f16_dconv() {
   static const bool v = [] {
     const char* e = getenv("HP_DCONV_16X16");
@@ -813,6 +1003,17 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
   const int zchunk = (Do + zsplit - 1) / zsplit;
   zsplit = (Do + zchunk - 1) / zchunk;
   dim3 grid((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)B, (unsigned)cog_n);
+  if (cin == 1 && cout == 1 && !stats && !use_mfma_c1()) {
+    static const int zc_env = getenv("HP_STENCIL_ZC") ? atoi(getenv("HP_STENCIL_ZC")) : 0;
+    const int zc = zc_env > 0 ? zc_env : (Do >= 256 ? 64 : std::max(8, (Do + 3) / 4));
+    dim3 g1((unsigned)((Wo + 255) / 256), (unsigned)((Ho + 3) / 4), (unsigned)(B * ((Do + zc - 1) / zc)));
+    if (padmode)
+      hipLaunchKernelGGL((k_stencil_c1<1>), g1, dim3(256), 0, st, x, w, bias, res, y, Di, Hi, Wi, Do, Ho, Wo, pad, flip, zc, slope);
+    else
+      hipLaunchKernelGGL((k_stencil_c1<0>), g1, dim3(256), 0, st, x, w, bias, res, y, Di, Hi, Wi, Do, Ho, Wo, pad, flip, zc, slope);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+  }
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * cout, st));
   if (!use_f16_dconv()) {
     if (padmode)
@@ -888,9 +1089,9 @@ extern "C" int hp_dconv3_backward_data(const float* gy, const float* w, float* g
     int rc = run_dconv(gy, w, nullptr, nullptr, dpad, nullptr, 1.0f, B, cout, cin, D, H, W, D + 2, H + 2, W + 2, 2, 27, (long)cin * 27, 1, 0, st);
     if (rc) return rc;
   }
-  const long total = (long)B * cin * D * H * W;
-  hipLaunchKernelGGL(k_fold_replicate, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, dpad, gx,
-                     (long)B * cin, D, H, W);
+  HP_REQUIRE((long)B * cin * D < 65536 && H < 65536, "hp_dconv3_backward_data: volume too large for the fold grid");
+  hipLaunchKernelGGL(k_fold_replicate, dim3((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)((long)B * cin * D)), dim3(256), 0,
+                     st, dpad, gx, D, H, W);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
