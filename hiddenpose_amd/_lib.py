@@ -83,6 +83,10 @@ SIGNATURES = {
     "hp_softargmax_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "hp_bce_dice_forward": (_i, [_fp, _fp, C.c_long, C.c_float, _vp, _fp, _vp]),
     "hp_bce_dice_backward": (_i, [_fp, _fp, _vp, _fp, _fp, C.c_long, C.c_float, _vp]),
+    "hp_weighted_mse_forward": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _fp, _vp]),
+    "hp_weighted_mse_backward": (_i, [_fp, _fp, _fp, _fp, C.c_long, C.c_float, _fp, _vp]),
+    "hp_depth_top4": (_i, [_fp, _fp, _fp, C.c_long, _i, C.c_long, _vp]),
+    "hp_noise_blur_poisson": (_i, [_fp, _fp, C.c_long, _fp, _i, _i, C.c_ulonglong, _vp]),
     "hp_bce_dice_partial": (_i, [_fp, _fp, C.c_long, _vp, _vp]),
     "hp_bce_dice_finalize": (_i, [_vp, C.c_long, C.c_float, _fp, _vp]),
     "hp_bce_dice_backward_scaled": (_i, [_fp, _fp, _vp, _fp, _fp, C.c_long, C.c_float, C.c_float, _vp]),

@@ -298,6 +298,124 @@ __global__ __launch_bounds__(MT) void k_bce_dice_bwd(const float* __restrict__ l
   }
 }
 
+
+// ---------------------------------------------------------------- weighted MSE on decoded joints (utils/criterion.py:156-162)
+// loss = sum((pred - gt)^2 * w) * scale   (scale = 1/B when size_average); one workgroup: n = 72 B elements
+__global__ __launch_bounds__(MT) void k_weighted_mse(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                     const float* __restrict__ wt, long n, float scale, float* __restrict__ loss) {
+  __shared__ float sh[MT / 64];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += MT) {
+    const float d = pred[i] - gt[i];
+    a += d * d * wt[i];
+  }
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < MT / 64; ++w) s += sh[w];
+    loss[0] = s * scale;
+  }
+}
+__global__ __launch_bounds__(MT) void k_weighted_mse_bwd(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                         const float* __restrict__ wt, const float* __restrict__ gl, long n,
+                                                         float scale, float* __restrict__ dpred) {
+  const float g = gl[0] * 2.0f * scale;
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < n; i += (long)gridDim.x * MT) dpred[i] = g * (pred[i] - gt[i]) * wt[i];
+}
+
+// ---------------------------------------------------------------- VisibleNet (models/feature_propagation.py:289-312)
+// x (planes = B*C, D, HW), already ReLU'd and normalised: the four largest values along depth per (plane, pixel), in
+// descending order (ties: the smaller depth index first), and their depth coordinate (D-1-idx)/(D-1).
+// out: vals (planes, 4, HW) and dep (planes, 4, HW).
+__global__ __launch_bounds__(MT) void k_depth_top4(const float* __restrict__ x, float* __restrict__ vals, float* __restrict__ dep,
+                                                   long planes, int D, long HW) {
+  const long total = planes * HW;
+  for (long i = (long)blockIdx.x * MT + threadIdx.x; i < total; i += (long)gridDim.x * MT) {
+    const long pl = i / HW, px = i - pl * HW;
+    const float* p = x + pl * D * HW + px;
+    float v0 = -INFINITY, v1 = -INFINITY, v2 = -INFINITY, v3 = -INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    for (int d = 0; d < D; ++d) {
+      const float v = p[(long)d * HW];
+      if (v > v3) {  // strict: an equal value met later does not displace an earlier one
+        if (v > v0) { v3 = v2; i3 = i2; v2 = v1; i2 = i1; v1 = v0; i1 = i0; v0 = v; i0 = d; }
+        else if (v > v1) { v3 = v2; i3 = i2; v2 = v1; i2 = i1; v1 = v; i1 = d; }
+        else if (v > v2) { v3 = v2; i3 = i2; v2 = v; i2 = d; }
+        else { v3 = v; i3 = d; }
+      }
+    }
+    const float inv = 1.0f / (float)(D - 1);
+    float* vo = vals + pl * 4 * HW + px;
+    float* dq = dep + pl * 4 * HW + px;
+    vo[0] = v0; vo[HW] = v1; vo[2 * HW] = v2; vo[3 * HW] = v3;
+    dq[0] = (float)(D - 1 - i0) * inv; dq[HW] = (float)(D - 1 - i1) * inv;
+    dq[2 * HW] = (float)(D - 1 - i2) * inv; dq[3 * HW] = (float)(D - 1 - i3) * inv;
+  }
+}
+
+// ---------------------------------------------------------------- noise augmentation (utils/nlos_pose_dataloader_noise.py:167-172)
+// Gaussian blur of the FLATTENED measurement (one long 1-D signal, replicate border) with K = 2R+1 normalised taps, then
+// one Poisson draw per sample with the blurred value as its mean (counter-based generator: sample i depends only on
+// (seed, i), so the result does not depend on the launch geometry).
+__device__ __forceinline__ unsigned int hp_hash32(unsigned int a, unsigned int b) {
+  unsigned int h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u + (a << 6) + (a >> 2));
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ float hp_uniform(unsigned long long seed, unsigned long long idx, unsigned int k) {
+  const unsigned int h = hp_hash32(hp_hash32((unsigned int)seed ^ (unsigned int)(idx >> 32), (unsigned int)idx),
+                                   (unsigned int)(seed >> 32) + 0x632BE5ABu * (k + 1u));
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+}
+__device__ float hp_poisson(float lam, unsigned long long seed, unsigned long long idx) {
+  if (!(lam > 0.f)) return 0.f;
+  if (lam < 12.f) {  // multiplication method (Knuth): exact
+    const float L = __expf(-lam);
+    float prod = 1.f;
+    unsigned int k = 0;
+    do {
+      prod *= hp_uniform(seed, idx, k);
+      ++k;
+    } while (prod > L && k < 200u);
+    return (float)(k - 1);
+  }
+  // transformed rejection (Hoermann's PTRS): exact for lam >= 10
+  const float slam = sqrtf(lam), loglam = __logf(lam);
+  const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+  const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+  for (unsigned int k = 0; k < 64u; ++k) {
+    const float U = hp_uniform(seed, idx, 2 * k) - 0.5f, V = hp_uniform(seed, idx, 2 * k + 1);
+    const float us = 0.5f - fabsf(U);
+    const float kf = floorf((2.f * a / us + b) * U + lam + 0.43f);
+    if (us >= 0.07f && V <= vr) return kf;
+    if (kf < 0.f || (us < 0.013f && V > us)) continue;
+    if (__logf(V) + __logf(invalpha) - __logf(a / (us * us) + b) <= -lam + kf * loglam - lgammaf(kf + 1.f)) return kf;
+  }
+  return floorf(lam + 0.5f);
+}
+__global__ __launch_bounds__(MT) void k_blur1d_poisson(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                       const float* __restrict__ taps, int R, int do_poisson,
+                                                       unsigned long long seed) {
+  extern __shared__ float sm[];  // taps (2R+1) then the tile with its halo (MT + 2R)
+  float* tp = sm;
+  float* tile = sm + (2 * R + 1);
+  for (int i = threadIdx.x; i < 2 * R + 1; i += MT) tp[i] = taps[i];
+  const long base = (long)blockIdx.x * MT;
+  for (int i = threadIdx.x; i < MT + 2 * R; i += MT) {
+    long j = base + i - R;
+    j = j < 0 ? 0 : (j >= n ? n - 1 : j);  // BORDER_REPLICATE
+    tile[i] = x[j];
+  }
+  __syncthreads();
+  const long o = base + threadIdx.x;
+  if (o >= n) return;
+  float s = 0.f;
+  for (int k = 0; k <= 2 * R; ++k) s = fmaf(tp[k], tile[threadIdx.x + k], s);
+  y[o] = do_poisson ? hp_poisson(s, seed, (unsigned long long)o) : s;
+}
+
 static unsigned mgrid(long n) { return (unsigned)std::max<long>(1, std::min<long>((n + MT - 1) / MT, 256 * 8)); }
 
 }  // namespace hp
@@ -427,6 +545,42 @@ extern "C" int hp_bce_dice_finalize(const double* acc, long n, float eps, float*
   HP_REQUIRE(acc && loss && n > 0, "hp_bce_dice_finalize: bad argument");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_bce_dice_finish, dim3(1), dim3(1), 0, st, acc, n, eps, loss);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_weighted_mse_forward(const float* pred, const float* gt, const float* weights, long n, float scale, float* loss,
+                                       void* stream) {
+  HP_REQUIRE(pred && gt && weights && loss && n > 0, "hp_weighted_mse_forward: bad argument");
+  hipLaunchKernelGGL(k_weighted_mse, dim3(1), dim3(MT), 0, (hipStream_t)stream, pred, gt, weights, n, scale, loss);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_weighted_mse_backward(const float* pred, const float* gt, const float* weights, const float* gloss, long n,
+                                        float scale, float* dpred, void* stream) {
+  HP_REQUIRE(pred && gt && weights && gloss && dpred && n > 0, "hp_weighted_mse_backward: bad argument");
+  hipLaunchKernelGGL(k_weighted_mse_bwd, dim3(mgrid(n)), dim3(MT), 0, (hipStream_t)stream, pred, gt, weights, gloss, n, scale, dpred);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_depth_top4(const float* x, float* vals, float* dep, long planes, int D, long HW, void* stream) {
+  HP_REQUIRE(x && vals && dep && planes > 0 && D >= 4 && HW > 0, "hp_depth_top4: bad argument (depth must be >= 4)");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("depth_top4", st);
+  hipLaunchKernelGGL(k_depth_top4, dim3(mgrid(planes * HW)), dim3(MT), 0, st, x, vals, dep, planes, D, HW);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_noise_blur_poisson(const float* x, float* y, long n, const float* taps, int radius, int do_poisson,
+                                     unsigned long long seed, void* stream) {
+  HP_REQUIRE(x && y && taps && n > 0 && radius >= 0 && radius <= 2048, "hp_noise_blur_poisson: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("noise_blur_poisson", st);
+  const size_t shm = sizeof(float) * (size_t)(2 * radius + 1 + MT + 2 * radius);
+  hipLaunchKernelGGL(k_blur1d_poisson, dim3((unsigned)((n + MT - 1) / MT)), dim3(MT), shm, st, x, y, n, taps, radius, do_poisson, seed);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

@@ -176,3 +176,26 @@ def normalize_feature(data_bxcxdxhxw):
     from . import hip_ops
 
     return hip_ops.normalize_feature(data_bxcxdxhxw)
+
+
+def normalize(data_bxcxdxhxw):
+    """models/feature_propagation.py:260-270: (x - min) / (max(x - min) + 1e-15) per (b, c)."""
+    from . import hip_ops
+
+    return hip_ops.normalize_feature(data_bxcxdxhxw) * 0.1   # the kernel's gain is 10 (normalize_feature)
+
+
+class VisibleNet(nn.Module):
+    """models/feature_propagation.py:289-312: relu -> normalize -> x 1e5 -> top-4 along depth; values and depth
+    coordinates (D-1-idx)/(D-1) concatenated on the channel axis.  (B,C,D,H,W) -> (B,2C,4,H,W).  The reference builds
+    it only for its `posenet2d` backbone and never calls it (models/NlosPose.py:41-59); inference only."""
+
+    def __init__(self, basedim, layernum=0):
+        super().__init__()
+        self.layernum = layernum
+
+    @torch.no_grad()
+    def forward(self, x):
+        from . import hip_ops
+
+        return hip_ops.visible_projection(x)

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 HIP_STAGES = {"feature_extraction", "lct_forward", "lct_backward", "normalize_feature", "unet3d", "posenet3d_50",
-              "softmax_integral", "bce_dice"}
+              "softmax_integral", "weighted_mse", "bce_dice"}
 ATEN_STAGES = {"Adam"}
 
 
@@ -894,6 +894,86 @@ class _SoftArgmax(torch.autograd.Function):
 def softmax_integral(preds, num_joints, W, H, D):
     """soft-argmax in voxel units, order (x,y,z) = (W,H,D axis) (utils/criterion.py:96-153) -> (B, 3J)."""
     return _SoftArgmax.apply(preds, num_joints, W, H, D)
+
+
+class _WeightedMse(torch.autograd.Function):
+    """sum((pred - gt)^2 * w) * scale  (utils/criterion.py:156-162; scale = 1/B when size_average)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, w, scale):
+        _need_cuda(pred, "weighted_mse")
+        pred, gt, w = pred.contiguous().float(), gt.contiguous().float(), w.contiguous().float()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.lib().hp_weighted_mse_forward(pred.data_ptr(), gt.data_ptr(), w.data_ptr(), pred.numel(), scale,
+                                                          loss.data_ptr(), _stream(pred)), "hp_weighted_mse_forward")
+        ctx.save_for_backward(pred, gt, w)
+        ctx.scale = scale
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        pred, gt, w = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        gl = gl.reshape(1).contiguous().float()
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.lib().hp_weighted_mse_backward(pred.data_ptr(), gt.data_ptr(), w.data_ptr(), gl.data_ptr(),
+                                                           pred.numel(), ctx.scale, d.data_ptr(), _stream(pred)),
+                       "hp_weighted_mse_backward")
+        return d, None, None, None
+
+
+def weighted_mse(pred, gt, weights, size_average=True):
+    return _WeightedMse.apply(pred, gt, weights, (1.0 / len(pred)) if size_average else 1.0)
+
+
+def visible_projection(x):
+    """VisibleNet.forward (models/feature_propagation.py:296-312): relu -> per-volume min-max normalisation -> x 1e5 ->
+    the 4 largest values along depth and their depth coordinates, concatenated on the channel axis:
+    (B, C, D, H, W) -> (B, 2C, 4, H, W).  Forward only (the reference builds the module for its unused 2-D backbone)."""
+    _need_cuda(x, "visible_projection")
+    L = _lib.lib()
+    x = x.contiguous().float()
+    b, c, d, h, w = x.shape
+    st = _stream(x)
+    with torch.cuda.device(x.device):
+        r = torch.empty_like(x)
+        _lib.check(L.hp_leaky_add_forward(x.data_ptr(), None, r.data_ptr(), x.numel(), 0.0, st), "hp_leaky_add_forward")  # ReLU
+        nrm = torch.empty_like(x)
+        keys = torch.empty(2 * b * c, dtype=torch.int64, device=x.device)
+        _lib.check(L.hp_normalize_feature_forward(r.data_ptr(), nrm.data_ptr(), b * c, d * h * w, 1.0e5, keys.data_ptr(), st),
+                   "hp_normalize_feature_forward")
+        out = torch.empty(b, 2 * c, 4, h, w, dtype=torch.float32, device=x.device)
+        for i in range(b):   # values / depths are the two channel halves of sample i
+            _lib.check(L.hp_depth_top4(nrm[i].data_ptr(), out[i, :c].data_ptr(), out[i, c:].data_ptr(), c, d, h * w, st),
+                       "hp_depth_top4")
+    return out
+
+
+def gaussian_taps(sigma: float):
+    """Normalised taps OpenCV's GaussianBlur uses for float images with ksize = (0, 0): 2 * round(4 sigma) + 1 taps
+    (cv2.getGaussianKernel: exp(-x^2 / (2 sigma^2)) / sum)."""
+    import numpy as np
+
+    k = int(round(sigma * 4 * 2 + 1)) | 1
+    r = k // 2
+    xs = np.arange(-r, r + 1, dtype=np.float64)
+    g = np.exp(-(xs * xs) / (2.0 * sigma * sigma))
+    return (g / g.sum()).astype(np.float32), r
+
+
+def add_noise(meas, sigma=10.61, seed=0, poisson=True):
+    """addnoise_dataset (utils/nlos_pose_dataloader_noise.py:167-172) on the device: Gaussian blur (sigma 10.61 =
+    25 / 2.355 bins) of the FLATTENED measurement with a replicate border, then a Poisson draw per sample."""
+    _need_cuda(meas, "add_noise")
+    x = meas.contiguous().float()
+    taps, r = gaussian_taps(sigma)
+    t = torch.from_numpy(taps).to(x.device)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().hp_noise_blur_poisson(x.data_ptr(), y.data_ptr(), x.numel(), t.data_ptr(), r, 1 if poisson else 0,
+                                                    int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(x)), "hp_noise_blur_poisson")
+    return y
 
 
 class _BceDice(torch.autograd.Function):

@@ -278,6 +278,19 @@ int hp_normalize_feature_backward(const float* dy, const float* x, float* dx, in
 int hp_softargmax_forward(const float* heat, float* joints, float* stat, int BJ, int D, int H, int W, void* stream);
 int hp_softargmax_backward(const float* heat, const float* joints, const float* stat, const float* gjoints, float* dheat,
                            int BJ, int D, int H, int W, void* stream);
+/* weighted_mse_loss (utils/criterion.py:156-162): loss = sum((pred - gt)^2 * weights) * scale, scale = 1/B */
+int hp_weighted_mse_forward(const float* pred, const float* gt, const float* weights, long n, float scale, float* loss,
+                            void* stream);
+int hp_weighted_mse_backward(const float* pred, const float* gt, const float* weights, const float* gloss, long n, float scale,
+                             float* dpred, void* stream);
+/* VisibleNet's projection (models/feature_propagation.py:303-310): per (plane, pixel) the 4 largest values along depth
+ * (descending) and their depth coordinate (D-1-idx)/(D-1); x (planes, D, HW) -> vals, dep (planes, 4, HW) */
+int hp_depth_top4(const float* x, float* vals, float* dep, long planes, int D, long HW, void* stream);
+/* addnoise_dataset (utils/nlos_pose_dataloader_noise.py:167-172): replicate-border Gaussian blur of the flattened
+ * measurement with 2*radius+1 normalised taps, then (do_poisson) one Poisson draw per sample, mean = blurred value;
+ * sample i is a function of (seed, i) only */
+int hp_noise_blur_poisson(const float* x, float* y, long n, const float* taps, int radius, int do_poisson,
+                          unsigned long long seed, void* stream);
 /* BCEDiceLoss (utils/criterion.py:348-385): BCEWithLogits(mean) + 1 - (2 sum(sig t) + eps)/(sum sig + sum t) over all
  * n elements.  acc: 4 doubles kept for backward. */
 int hp_bce_dice_forward(const float* logit, const float* target, long n, float eps, double* acc, float* loss,

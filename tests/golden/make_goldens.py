@@ -307,6 +307,17 @@ def sec_specular():
     print(f"  specular: |y| {y.norm().item():.4g} |gx| {x.grad.norm().item():.4g}")
 
 
+def sec_visible():
+    """VisibleNet (models/feature_propagation.py:289-312) on a volume without ties among its four largest values."""
+    from models.feature_propagation import VisibleNet
+
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 12, 9, 10, generator=gen)
+    y = VisibleNet(basedim=3)(x)
+    save("visible_net.npz", x=x.numpy(), y=y.numpy())
+    print(f"  VisibleNet: {tuple(x.shape)} -> {tuple(y.shape)}")
+
+
 E2E128_PARAMS = ["feature_extraction.weights", "feature_extraction.conv1.1.weight", "feature_extraction.conv1.3.tmp.4.bias",
                  "autoencoder.conv.double_conv.0.weight", "autoencoder.dec4.conv.double_conv.3.weight", "autoencoder.out.conv.bias",
                  "pose_net.conv1.weight", "pose_net.bn1.weight", "pose_net.layer1.0.conv2.weight", "pose_net.layer2.0.conv2.weight",
@@ -625,7 +636,7 @@ def sec_ingest():
 
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
-            "specular": sec_specular, "e2e128train": sec_e2e128train, "highres": sec_highres}
+            "specular": sec_specular, "visible": sec_visible, "e2e128train": sec_e2e128train, "highres": sec_highres}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

