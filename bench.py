@@ -374,8 +374,9 @@ def main():
     ap.add_argument("--workload", default="t512", choices=sorted(WORKLOADS) + ["sformer", "highres", "ingest"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-precision", default="fp32", choices=["fp32", "bf16", "bf16x3", "bf16x6"],
-                    help="regressor convolution GEMM arithmetic; bf16 = BASELINE.json configs[2] (bf16 with fp32 LCT). "
+    ap.add_argument("--conv-precision", default="fp32", choices=["fp32", "bf16", "bf16s", "bf16x3", "bf16x6"],
+                    help="regressor convolution GEMM arithmetic; bf16s = BASELINE.json configs[2] in full (bf16 matrix cores and "
+                         "bf16 activation storage, fp32 LCT / statistics / weights); bf16 = bf16 matrix cores over fp32 tensors. "
                          "The headline metric (configs[1]) is fp32, the default.")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--wgrad-stream", action="store_true",
@@ -435,7 +436,7 @@ def main():
         _ops.set_wgrad_async(True)
     bf16 = args.conv_precision != "fp32"
     # split modes issue 3 / 6 bf16 MFMAs per algorithmic product: the useful-FLOP ceiling shrinks accordingly
-    mfma_terms = {"fp32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}[args.conv_precision]
+    mfma_terms = {"fp32": 1, "bf16": 1, "bf16s": 1, "bf16x3": 3, "bf16x6": 6}[args.conv_precision]
     mfma_peak = round(MFMA_BF16_PEAK_TFLOPS / mfma_terms, 1) if bf16 else MFMA_F32_PEAK_TFLOPS
     seed_everything(410)
     model = NlosPose(cfg).to(dev)
@@ -512,7 +513,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.conv_precision if bf16 else "f32", "data": "synthetic",
             "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
                                    f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
-                                   "accumulation) with fp32 LCT, U-Net, norms, losses and fp32 tensors in HBM" if bf16 else "fp32") + ", random-init weights"
+                                   "accumulation) with fp32 LCT, U-Net, norms, losses and " + ("bf16 regressor activations / activation gradients in HBM (fp32 raw conv outputs, statistics, weights)" if args.conv_precision == "bf16s" else "fp32 tensors in HBM") if bf16 else "fp32") + ", random-init weights"
                                    + (", weight gradients on a second stream (kernels overlap)" if args.wgrad_stream and world == 1 else ""),
                        "global_batch": B * world,
                        "parallelism": f"dp{world}" + (f" ({args.dp_algo}, {'bf16' if wire is not None else 'fp32'} wire, "

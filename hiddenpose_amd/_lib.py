@@ -46,12 +46,14 @@ SIGNATURES = {
     "hp_bn_train_finalize": (_i, [_vp, C.c_long, _i, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _vp]),
     "hp_bn_train_finalize_counted": (_i, [_vp, C.c_long, _i, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_bn_eval_stats": (_i, [_fp, _fp, _i, C.c_float, _fp, _fp, _vp]),
-    "hp_bn_apply": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _vp, _vp]),
-    "hp_bn_apply_res_bn": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _vp, _fp, _fp, _fp, _fp, _vp]),
+    "hp_bn_apply": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _vp, _i, _vp]),
+    "hp_bn_apply_res_bn": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _vp, _fp, _fp, _fp, _fp, _i, _vp]),
+    "hp_cast_f32_to_bf16": (_i, [_fp, _vp, C.c_long, _vp]),
+    "hp_cast_bf16_to_f32": (_i, [_vp, _fp, C.c_long, _vp]),
     "hp_bn_backward_workspace_bytes": (_sz, [_i]),
     "hp_bn_backward_dual": (_i, [_fp, _vp, C.c_long, _i, _fp, _fp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i,
-                                 _fp, _fp, _vp, _vp]),
-    "hp_bn_backward": (_i, [_fp, _fp, _fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _vp, _vp]),
+                                 _fp, _fp, _vp, _i, _vp]),
+    "hp_bn_backward": (_i, [_fp, _fp, _fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _vp, _i, _vp]),
     "hp_maxpool3d_k3s2_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "hp_maxpool3d_k3s2_backward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "hp_layout_transpose": (_i, [_fp, _fp, _i, C.c_long, _i, _i, _vp]),
@@ -107,7 +109,7 @@ SIGNATURES = {
 
 class ConvDesc(C.Structure):
     """Mirror of `hp_conv_desc` (include/hiddenpose_hip.h)."""
-    _fields_ = [(n, C.c_int) for n in ("B", "Di", "Hi", "Wi", "Cin", "Cout", "k", "stride", "pad", "transposed", "precision")]
+    _fields_ = [(n, C.c_int) for n in ("B", "Di", "Hi", "Wi", "Cin", "Cout", "k", "stride", "pad", "transposed", "precision", "io")]
 
 
 def lib() -> C.CDLL:

@@ -55,6 +55,8 @@ struct IgemmGeom {
   int kpt;                 // K tiles per tap (Cin/32, or padded taps/32 for the stem)
   int sw, sh, sd;          // log2 of gw, gh, gd when all three are powers of two, else -1
   int tn;                  // > 0: 1-D grid with the N tiles of one M tile adjacent on one XCD (set by the launcher)
+  int xh, yh, ah;          // element type of the gathered tensor / written tensor / addend: 0 = fp32, 1 = bf16 (hp_ld4 / hp_st4)
+  int wh;                  // packed weights are bf16 (bf16-storage tiles only)
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -172,22 +174,31 @@ struct TileCfg {
   static constexpr int TN = BN / (WN * 32);
 };
 
-template <int BN, bool STEM, bool STATS, int NP>
-__global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const float* __restrict__ X, const float* __restrict__ Wp,
-                                              const float* __restrict__ bias, float* __restrict__ Y,
-                                              double* __restrict__ stats, const float* __restrict__ addend,
+// XH: the gathered tensor is bf16 in memory (NP = 1 only): K tiles of 64 channels, so that a thread still moves 16 bytes per
+// row and load (8 bf16) -- half the loads, K tiles and barriers per MAC of the fp32-storage path -- and the A tile goes to
+// LDS as loaded, without a conversion.
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false>
+__global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
+                                              const float* __restrict__ bias, void* __restrict__ Y,
+                                              double* __restrict__ stats, const void* __restrict__ addend,
                                               const unsigned char* __restrict__ amask, IgemmGeom g) {
+  const float* const X = (const float*)Xv;  // fp32 view (stem: always fp32; otherwise only used when g.xh == 0)
   using C = TileCfg<BN>;
   // one LDS arena: A and B tiles during the K loop, then the output staging tile of the epilogue
   constexpr bool BF = NP > 0;  // NP = 0: exact-fp32 MFMA; NP >= 1: bf16 MFMA on NP operand planes
   constexpr int NPL = NP > 0 ? NP : 1;
-  constexpr int ARENA = (BM + BN) * LDK > NP * (BM + BN) * LDH / 2 ? (BM + BN) * LDK : NP * (BM + BN) * LDH / 2;
+  static_assert(!XH || (NP == 1 && !STEM), "bf16-storage tiles: single bf16 plane, not the stem");
+  constexpr int BKT = XH ? 64 : BK;      // K extent of a tile
+  constexpr int LDX = BKT + 8;           // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
+  constexpr int EPL = XH ? 8 : 4;        // elements per thread, row and load
+  constexpr int ARENA0 = (BM + BN) * LDK > NP * (BM + BN) * LDH / 2 ? (BM + BN) * LDK : NP * (BM + BN) * LDH / 2;
+  constexpr int ARENA = XH && (BM + BN) * LDX / 2 > ARENA0 ? (BM + BN) * LDX / 2 : ARENA0;
   __shared__ __attribute__((aligned(16))) float smem[ARENA];
   float* const As = smem;
   float* const Bs = smem + BM * LDK;
   // BF: the same arena holds the tiles as NP bf16 planes each (operands split once, on the way into LDS)
   __bf16* const Ah = (__bf16*)smem;
-  __bf16* const Bh = Ah + NPL * BM * LDH;
+  __bf16* const Bh = Ah + NPL * BM * (XH ? LDX : LDH);
   __shared__ float red[STATS ? 2 * BN * C::WM : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / C::WN, wn = wave % C::WN;
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     rz[i] *= g.s;
   }
   const int ntaps = STEM ? 1 : class_ntaps(g, cls);
-  const int KT = ntaps * g.kpt;
+  const int kpt = XH ? (g.Cin + BKT - 1) / BKT : g.kpt;
+  const int KT = ntaps * kpt;
 
   // Gather addressing without per-tile index arithmetic: element offset = rowoff[i] (this thread's voxel and
   // channel quad, fixed) + a wave-uniform tap offset; whether tap t falls inside the volume for row i is decided
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   bool wvalid[BN / 32];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    rowoff[i] = ((((long)rb[i] * g.Di + rz[i]) * g.Hi + ry[i]) * g.Wi + rx[i]) * g.Cin + kq * 4;
+    rowoff[i] = ((((long)rb[i] * g.Di + rz[i]) * g.Hi + ry[i]) * g.Wi + rx[i]) * g.Cin + kq * EPL;
     vmask[i] = 0ull;
   }
   if constexpr (!STEM) {
@@ -251,10 +263,13 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   for (int i = 0; i < BN / 32; ++i) {
     const int n = n0 + r0 + 32 * i;
     wvalid[i] = n < g.Nout;
-    wrow[i] = (long)n * g.Cin + kq * 4;
+    wrow[i] = (long)n * g.Cin + kq * EPL;
   }
 
   float4 ra[4], rbw[BN / 32];
+  uint4 ra8[XH ? 4 : 1];        // XH: 8 bf16 per row as loaded
+  float4 rbw2[XH ? BN / 32 : 1];  // XH: second half of the 8 weights per row (fp32 weights)
+  uint4 rb8[XH ? BN / 32 : 1];    // XH: 8 bf16 weights per row (bf16 weights, g.wh)
   // running (tap, channel tile) of the NEXT tile to gather: no division in the K loop
   int ld_tap = 0, ld_ci = 0;
   long ld_xoff = 0, ld_woff = 0;  // wave-uniform: tap displacement in X, tap slab in the packed weights
@@ -289,17 +304,36 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         rbw[i] = n < g.Nout ? *(const float4*)(Wp + (long)n * (g.kpt * BK) + kbase) : make_float4(0, 0, 0, 0);
       }
     } else {
-      const int cofs = ld_ci * BK;
-      const bool cok = cofs + kq * 4 < g.Cin;
-      const float* const xb = X + (ld_xoff + cofs);
+      const int cofs = ld_ci * BKT;
+      const bool cok = cofs + kq * EPL < g.Cin;
+      const long xb = ld_xoff + cofs;
       const float* const wb = Wp + (ld_woff + cofs);
+      if constexpr (XH) {
+        const unsigned short* const xh = (const unsigned short*)Xv + xb;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ra[i] = (cok && (vmask[i] & 1ull)) ? *(const float4*)(xb + rowoff[i]) : make_float4(0, 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+          ra8[i] = (cok && (vmask[i] & 1ull)) ? *(const uint4*)(xh + rowoff[i]) : make_uint4(0u, 0u, 0u, 0u);
+        if (g.wh) {
+          const unsigned short* const wb16 = (const unsigned short*)Wp + (ld_woff + cofs);
 #pragma unroll
-      for (int i = 0; i < BN / 32; ++i)
-        rbw[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i]) : make_float4(0, 0, 0, 0);
-      if (++ld_ci == g.kpt) {
+          for (int i = 0; i < BN / 32; ++i)
+            rb8[i] = (cok && wvalid[i]) ? *(const uint4*)(wb16 + wrow[i]) : make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+          for (int i = 0; i < BN / 32; ++i) {
+            rbw[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i]) : make_float4(0, 0, 0, 0);
+            rbw2[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i] + 4) : make_float4(0, 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          ra[i] = (cok && (vmask[i] & 1ull)) ? hp_ld4(Xv, xb + rowoff[i], g.xh) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+          rbw[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i]) : make_float4(0, 0, 0, 0);
+      }
+      if (++ld_ci == kpt) {
         ld_ci = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) vmask[i] >>= 1;
@@ -308,6 +342,22 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     }
   };
   auto store_tile = [&]() {
+    if constexpr (XH) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(uint4*)(Ah + (r0 + 32 * i) * LDX + kq * 8) = ra8[i];
+      if (g.wh) {
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) *(uint4*)(Bh + (r0 + 32 * i) * LDX + kq * 8) = rb8[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+          const bf16x4 lo = to_bf16x4(rbw[i]), hi = to_bf16x4(rbw2[i]);
+          *(bf16x4*)(Bh + (r0 + 32 * i) * LDX + kq * 8) = lo;
+          *(bf16x4*)(Bh + (r0 + 32 * i) * LDX + kq * 8 + 4) = hi;
+        }
+      }
+      return;
+    }
     if constexpr (BF) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -353,22 +403,23 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
 
   const float* ap = As + (wm * C::TM * 32 + (lane & 31)) * LDK + (lane >> 5);
   const float* bp = Bs + (wn * C::TN * 32 + (lane & 31)) * LDK + (lane >> 5);
-  const __bf16* ahp = Ah + (wm * C::TM * 32 + (lane & 31)) * LDH + 8 * (lane >> 5);
-  const __bf16* bhp = Bh + (wn * C::TN * 32 + (lane & 31)) * LDH + 8 * (lane >> 5);
+  constexpr int LDF = XH ? LDX : LDH;  // bf16 fragment row stride
+  const __bf16* ahp = Ah + (wm * C::TM * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
+  const __bf16* bhp = Bh + (wn * C::TN * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   // kt = -1 is the prologue: one call site for the gather keeps the pipeline uniform
   for (int kt = -1; kt < KT; ++kt) {
     if (kt + 1 < KT) load_tile(kt + 1);
     if (BF && kt >= 0) {
       // v_mfma_f32_32x32x16_bf16: lane (row = lane&31, half = lane>>5) feeds k = 8*half .. 8*half+7
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
+      for (int ks = 0; ks < BKT / 16; ++ks) {
         bf16x8 ha[NPL][C::TM], hb[NPL][C::TN];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-          for (int i = 0; i < C::TM; ++i) ha[p][i] = *(const bf16x8*)(ahp + (p * BM + i * 32) * LDH + ks * 16);
+          for (int i = 0; i < C::TM; ++i) ha[p][i] = *(const bf16x8*)(ahp + (p * BM + i * 32) * LDF + ks * 16);
 #pragma unroll
-          for (int j = 0; j < C::TN; ++j) hb[p][j] = *(const bf16x8*)(bhp + (p * BN + j * 32) * LDH + ks * 16);
+          for (int j = 0; j < C::TN; ++j) hb[p][j] = *(const bf16x8*)(bhp + (p * BN + j * 32) * LDF + ks * 16);
         }
         using ST = SplitTerms<NPL>;
 #pragma unroll
@@ -447,14 +498,14 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
         }
         float4 v = *(const float4*)(smem + row64 * LDO + 4 * q);
-        float* yp = Y + orow * g.Nout + n;
+        const long yo = orow * g.Nout + n;
         if (vec_ok) {
           if (bias) {
             const float4 bv = *(const float4*)(bias + n);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           }
           if (addend) {
-            float4 av = *(const float4*)(addend + orow * g.Nout + n);
+            float4 av = hp_ld4(addend, yo, g.ah);
             if (amask) {  // byte per channel quad (hp_bn_apply's relu_mask): the addend is dy (.) mask, never stored
               const unsigned mk = amask[(orow * g.Nout + n) >> 2];
               av.x = (mk & 1u) ? av.x : 0.f;
@@ -464,12 +515,12 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
             }
             v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
           }
-          *(float4*)yp = v;
+          hp_st4(Y, yo, v, g.yh);
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int e = 0; e < 4; ++e)
             if (n + e < g.Nout)
-              yp[e] = vv[e] + (bias ? bias[n + e] : 0.f) + (addend ? addend[orow * g.Nout + n + e] : 0.f);
+              hp_st1(Y, yo + e, vv[e] + (bias ? bias[n + e] : 0.f) + (addend ? hp_ld1(addend, yo + e, g.ah) : 0.f), g.yh);
         }
       }
     }
@@ -491,7 +542,8 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         for (int j = 0; j < C::TN; ++j) {
           const int n = n0 + wn * C::TN * 32 + j * 32 + (lane & 31);
           if (n < g.Nout)
-            Y[orow * g.Nout + n] = acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? addend[orow * g.Nout + n] : 0.f);
+            hp_st1(Y, orow * g.Nout + n,
+                   acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? hp_ld1(addend, orow * g.Nout + n, g.ah) : 0.f), g.yh);
         }
       }
     }
@@ -545,13 +597,19 @@ constexpr int WG_KM = 32;  // voxels per step
 // step, global loads of step s+1 in flight while the MFMAs of step s run.  With TT = 64 a block may own
 // NTAP consecutive taps of a single-class convolution: the dY tile is staged once and reused by the
 // NTAP gathered X tiles (1 + NTAP LDS fragment reads feed NTAP MFMAs).
-template <bool STEM, int TT, int NTAP, int NP>
-__global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
+// XH: X and dY are both bf16 in memory (NP = 1): rows are staged with 16-byte loads of 8 bf16 -- half the load
+// instructions per step -- and go to LDS as loaded.
+template <bool STEM, int TT, int NTAP, int NP, bool XH = false>
+__global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const void* __restrict__ dY,
                                               float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit,
                                               int tiles_total, int tap_groups) {
-  constexpr int QN = TT / 4;            // float4 per staged row
+  const float* const X = (const float*)Xv;  // stem: always fp32.  g.xh / g.yh: element type of X / dY
+  static_assert(!XH || (NP == 1 && !STEM), "bf16-storage staging: single bf16 plane, not the stem");
+  constexpr int EPL = XH ? 8 : 4;       // elements per thread, row and load
+  constexpr int QN = TT / EPL;          // 16-byte loads per staged row
   constexpr int RPP = CT / QN;          // rows per staging pass
   constexpr int RPT = WG_KM / RPP;      // rows per thread
+  static_assert(RPT >= 1, "staging pass covers at most one step");
   constexpr int WT = TT / 64;           // 32x32 tiles per wave per dim
   static_assert(NTAP == 1 || TT == 64, "multi-tap blocks use the 64x64 tile");
   constexpr bool BF = NP > 0;
@@ -614,7 +672,35 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
         for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
 
   float4 vy[RPT], vx[NTAP][RPT];
+  uint4 hy[XH ? RPT : 1], hx[XH ? NTAP : 1][XH ? RPT : 1];
   auto load_step = [&](long mb) {
+    if constexpr (XH) {
+      const unsigned short* const Xh16 = (const unsigned short*)Xv;
+      const unsigned short* const Yh16 = (const unsigned short*)dY;
+#pragma unroll
+      for (int h = 0; h < RPT; ++h) {
+        const long m = mb + sr + RPP * h;
+        hy[h] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) hx[t][h] = make_uint4(0u, 0u, 0u, 0u);
+        if (m < mend) {
+          int b, z, y, x;
+          grid_coords(g, m, b, z, y, x);
+          const long orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
+          const int n = n0 + sq * 8;
+          if (n + 7 < g.Nout) hy[h] = *(const uint4*)(Yh16 + orow * g.Nout + n);
+          const int c = c0 + sq * 8;
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) {
+            const int zz = z * g.s + dz[t], yy = y * g.s + dy[t], xx = x * g.s + dx[t];
+            if (tv[t] && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
+                c + 7 < g.Cin)
+              hx[t][h] = *(const uint4*)(Xh16 + (long)(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < RPT; ++h) {
       const long m = mb + sr + RPP * h;
@@ -627,11 +713,11 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
         const long orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
         const int n = n0 + sq * 4;
         if (n + 3 < g.Nout) {
-          vy[h] = *(const float4*)(dY + orow * g.Nout + n);
+          vy[h] = hp_ld4(dY, orow * g.Nout + n, g.yh);
         } else if (n < g.Nout) {
           float t4[4] = {0, 0, 0, 0};
           for (int e = 0; e < 4; ++e)
-            if (n + e < g.Nout) t4[e] = dY[orow * g.Nout + n + e];
+            if (n + e < g.Nout) t4[e] = hp_ld1(dY, orow * g.Nout + n + e, g.yh);
           vy[h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
         if constexpr (STEM) {
@@ -653,7 +739,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
             const int zz = z * g.s + dz[t], yy = y * g.s + dy[t], xx = x * g.s + dx[t];
             if (tv[t] && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
                 c < g.Cin)
-              vx[t][h] = *(const float4*)(X + (long)(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
+              vx[t][h] = hp_ld4(Xv, (long)(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c, g.xh);
           }
         }
       }
@@ -665,7 +751,11 @@ __global__ __launch_bounds__(CT) void k_wgrad(const float* __restrict__ X, const
     __syncthreads();  // fragment reads of the previous step are done
 #pragma unroll
     for (int h = 0; h < RPT; ++h) {
-      if constexpr (BF) {
+      if constexpr (XH) {
+        *(uint4*)(Yh + (sr + RPP * h) * LDT + sq * 8) = hy[h];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) *(uint4*)(Xh + (t * WG_KM + sr + RPP * h) * LDT + sq * 8) = hx[t][h];
+      } else if constexpr (BF) {
         bf16x4 pl[NPL];
         split_bf16<NPL>(vy[h], pl);
 #pragma unroll
@@ -1328,7 +1418,8 @@ __global__ void k_pack_weight(const float* __restrict__ w, float* __restrict__ o
 // The same mapping through a 64 x taps LDS tile so that BOTH sides move contiguous runs: the torch side in runs
 // of `taps` floats (t fastest), the packed side in runs of 64 inner channels.  grid (inner chunks of 64, outer).
 __global__ __launch_bounds__(256) void k_pack_weight_tiled(const float* __restrict__ w, float* __restrict__ out, int Cout,
-                                                           int Cin, int taps, int transposed, int swap, int to_torch) {
+                                                           int Cin, int taps, int transposed, int swap, int to_torch,
+                                                           int out_half = 0) {
   __shared__ float tile[64][65];
   const int A = swap ? Cin : Cout, Bn = swap ? Cout : Cin;  // packed [t][A][Bn]
   const int a = blockIdx.y, bn0 = blockIdx.x * 64;
@@ -1345,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_pack_weight_tiled(const float* __restri
     __syncthreads();
     for (int e = threadIdx.x; e < taps * 64; e += 256) {
       const int t = e >> 6, bl = e & 63;
-      if (bl < nb) out[((long)t * A + a) * Bn + bn0 + bl] = tile[bl][t];
+      if (bl < nb) hp_st1(out, ((long)t * A + a) * Bn + bn0 + bl, tile[bl][t], out_half);
     }
   } else {
     for (int e = threadIdx.x; e < taps * 64; e += 256) {
@@ -1459,26 +1550,30 @@ static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
   return HP_OK;
 }
 
-template <bool STEM, bool STATS, int NP>
-static void launch_igemm_bn(const IgemmGeom& g, int classes, const float* X, const float* W, const float* bias, float* Y,
-                            double* stats, const float* addend, const unsigned char* amask, hipStream_t st) {
+template <bool STEM, bool STATS, int NP, bool XH = false>
+static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, const float* W, const float* bias, void* Y,
+                            double* stats, const void* addend, const unsigned char* amask, hipStream_t st) {
+  if constexpr (NP == 1 && !STEM && !XH) {
+    // bf16 tensor in memory, channels a multiple of 64: the 64-deep K tile variant
+    if (g.xh && g.Cin % 64 == 0) return launch_igemm_bn<STEM, STATS, NP, true>(g, classes, X, W, bias, Y, stats, addend, amask, st);
+  }
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
   if (g.Nout > 64) {
     const unsigned tn = (unsigned)((g.Nout + 127) / 128);
     IgemmGeom gg = g;
     gg.tn = tn > 1 ? (int)tn : 0;  // XCD-aware 1-D grid (see k_igemm)
     const dim3 grid = tn > 1 ? dim3((mt + 7) / 8 * 8 * tn, 1, classes) : dim3(mt, 1, classes);
-    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
+    hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP, XH>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
   } else if (g.Nout > 32) {
-    hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
+    hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP, XH>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
   } else {
-    hipLaunchKernelGGL((k_igemm<32, STEM, STATS, NP>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
+    hipLaunchKernelGGL((k_igemm<32, STEM, STATS, NP, XH>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
   }
 }
 
 template <int NP>
-static void launch_igemm_p(const IgemmGeom& g, int classes, bool stem, const float* X, const float* W, const float* bias,
-                           float* Y, double* stats, const float* addend, const unsigned char* amask, hipStream_t st) {
+static void launch_igemm_p(const IgemmGeom& g, int classes, bool stem, const void* X, const float* W, const float* bias,
+                           void* Y, double* stats, const void* addend, const unsigned char* amask, hipStream_t st) {
   if (stem) {
     if (stats) launch_igemm_bn<true, true, NP>(g, classes, X, W, bias, Y, stats, addend, amask, st);
     else launch_igemm_bn<true, false, NP>(g, classes, X, W, bias, Y, stats, addend, amask, st);
@@ -1488,8 +1583,8 @@ static void launch_igemm_p(const IgemmGeom& g, int classes, bool stem, const flo
   }
 }
 
-static void launch_igemm(const IgemmGeom& g, int classes, bool stem, int planes, const float* X, const float* W,
-                         const float* bias, float* Y, double* stats, const float* addend, hipStream_t st,
+static void launch_igemm(const IgemmGeom& g, int classes, bool stem, int planes, const void* X, const float* W,
+                         const float* bias, void* Y, double* stats, const void* addend, hipStream_t st,
                          const unsigned char* amask = nullptr) {
   switch (planes) {
     case 1: launch_igemm_p<1>(g, classes, stem, X, W, bias, Y, stats, addend, amask, st); break;
@@ -1509,8 +1604,10 @@ extern "C" size_t hp_conv3d_packed_weight_elems(const hp_conv_desc* d) {
   return (size_t)d->Cout * d->Cin * d->k * d->k * d->k;
 }
 
-extern "C" int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, float* w_fwd, float* w_dgrad,
+extern "C" int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, void* w_fwd_v, void* w_dgrad_v,
                                      void* stream) {
+  float* const w_fwd = (float*)w_fwd_v;      // bf16 images (HP_IO_W_BF16) are written through hp_st1
+  float* const w_dgrad = (float*)w_dgrad_v;
   HP_REQUIRE(d && w_torch, "hp_conv3d_pack_weight: null argument");
   ConvPlan p;
   int rc = make_plan(*d, p);
@@ -1525,12 +1622,13 @@ extern "C" int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch
   } else {
     HP_REQUIRE(taps <= 64, "conv: at most 64 taps (got %d)", taps);
     HP_PROF("conv_pack_weight", st);
+    const int wh = (d->io & HP_IO_W_BF16) ? 1 : 0;  // packed images as bf16 (the bf16-storage tiles read them as they lie)
     if (w_fwd)
       hipLaunchKernelGGL(k_pack_weight_tiled, dim3((d->Cin + 63) / 64, d->Cout), dim3(256), 0, st, w_torch, w_fwd, d->Cout,
-                         d->Cin, taps, d->transposed, 0, 0);
+                         d->Cin, taps, d->transposed, 0, 0, wh);
     if (w_dgrad)
       hipLaunchKernelGGL(k_pack_weight_tiled, dim3((d->Cout + 63) / 64, d->Cin), dim3(256), 0, st, w_torch, w_dgrad, d->Cout,
-                         d->Cin, taps, d->transposed, 1, 0);
+                         d->Cin, taps, d->transposed, 1, 0, wh);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
@@ -1554,15 +1652,21 @@ extern "C" int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_pac
   return HP_OK;
 }
 
-extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd, const float* bias, float* y,
+extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const void* x, const float* w_fwd, const float* bias, void* y,
                                  double* stats, void* stream) {
   HP_REQUIRE(d && x && w_fwd && y, "hp_conv3d_forward: null argument");
   ConvPlan p;
   int rc = make_plan(*d, p);
   if (rc) return rc;
+  HP_REQUIRE(!(p.stem && (d->io & HP_IO_X_BF16)), "hp_conv3d_forward: the stem reads its single-channel input as fp32");
+  p.fwd.xh = (d->io & HP_IO_X_BF16) ? 1 : 0;
+  p.fwd.yh = (d->io & HP_IO_Y_BF16) ? 1 : 0;
+  p.fwd.wh = (d->io & HP_IO_W_BF16) ? 1 : 0;
+  HP_REQUIRE(!p.fwd.wh || (p.fwd.xh && p.planes == 1 && !p.stem && d->Cin % 64 == 0),
+             "hp_conv3d_forward: bf16 packed weights go with a bf16 input, HP_PRECISION_BF16 and Cin %% 64 == 0");
   hipStream_t st = (hipStream_t)stream;
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
-  if (p.stem && p.planes == 0 && d->Cout == 64 && !bias) {
+  if (p.stem && p.planes == 0 && d->Cout == 64 && !bias && !p.fwd.yh) {
     // dedicated 4x4x1-MFMA stem kernel: ~1024 workgroups, one resident per CU (138 KB of LDS)
     const int tiles_x = (d->Wi + SF_TX - 1) / SF_TX, tiles_y = (d->Hi + SF_TY - 1) / SF_TY;
     const long cols = (long)tiles_x * tiles_y * d->B;
@@ -1578,8 +1682,8 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
     });
     HP_CHECK_HIP(lds_rc);
     HP_PROF("conv_igemm_stem", st);
-    hipLaunchKernelGGL(k_stem_fwd_mfma, dim3((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)d->B), dim3(256), lds, st, x, w_fwd,
-                       y, stats, d->Di, d->Hi, d->Wi, p.fwd.kpt * BK, tiles_x, tiles_y, zchunk);
+    hipLaunchKernelGGL(k_stem_fwd_mfma, dim3((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)d->B), dim3(256), lds, st,
+                       (const float*)x, w_fwd, (float*)y, stats, d->Di, d->Hi, d->Wi, p.fwd.kpt * BK, tiles_x, tiles_y, zchunk);
   } else {
     HP_PROF(p.stem ? "conv_igemm_stem" : d->transposed ? "conv_igemm_deconv" : d->k == 1 ? "conv_igemm_k1" : "conv_igemm_k3", st);
     launch_igemm(p.fwd, p.fwd_classes, p.stem, p.planes, x, w_fwd, bias, y, stats, nullptr, st);
@@ -1591,7 +1695,7 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const fl
 extern "C" int hp_linear_forward(const float* x, const float* w, const float* bias, const float* addend, float* y, long M, int K,
                                  int N, int precision, void* stream) {
   HP_REQUIRE(x && w && y && M >= 1 && M < (1l << 31) && K >= 4 && N >= 1, "hp_linear_forward: bad argument");
-  hp_conv_desc d{1, 1, 1, (int)M, K, N, 1, 1, 0, 0, precision};
+  hp_conv_desc d{1, 1, 1, (int)M, K, N, 1, 1, 0, 0, precision, 0};
   ConvPlan p;
   int rc = make_plan(d, p);
   if (rc) return rc;
@@ -1604,17 +1708,25 @@ extern "C" int hp_linear_forward(const float* x, const float* w, const float* bi
   return HP_OK;
 }
 
-extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                       const float* addend, void* stream) {
+extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx,
+                                       const void* addend, void* stream) {
   return hp_conv3d_backward_data_masked(d, dy, w_dgrad, dx, addend, nullptr, stream);
 }
 
-extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                              const float* addend, const unsigned char* addend_mask, void* stream) {
+extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx,
+                                              const void* addend, const unsigned char* addend_mask, void* stream) {
   HP_REQUIRE(d && dy && w_dgrad && dx, "hp_conv3d_backward_data: null argument");
   ConvPlan p;
   int rc = make_plan(*d, p);
   if (rc) return rc;
+  const int dyh = (d->io & HP_IO_DY_BF16) ? 1 : 0, dxh = (d->io & HP_IO_DX_BF16) ? 1 : 0;
+  HP_REQUIRE(!(p.stem && (dyh || dxh)), "hp_conv3d_backward_data: the stem's data gradient is fp32 in, fp32 out");
+  p.dgrad.xh = dyh;
+  p.dgrad.yh = p.dgrad.ah = dxh;
+  p.dgrad.wh = (d->io & HP_IO_W_BF16) ? 1 : 0;
+  HP_REQUIRE(!p.dgrad.wh || (dyh && p.planes == 1 && !p.stem && p.dgrad.Cin % 64 == 0),
+             "hp_conv3d_backward_data: bf16 packed weights go with a bf16 dy, HP_PRECISION_BF16 and Cout %% 64 == 0");
+  const size_t esz = dxh ? 2 : 4;
   HP_REQUIRE(!addend_mask || (addend && !p.stem && !p.dgrad_zero_fill && d->Cin % 4 == 0 && d->Cin > 32),
              "hp_conv3d_backward_data_masked: a masked addend needs a dense data gradient with > 32 input channels, a multiple of 4");
   hipStream_t st = (hipStream_t)stream;
@@ -1625,13 +1737,13 @@ extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float
     else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     HP_PROF("conv_stem_dgrad", st);
-    hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, dy, w_dgrad, dx,
+    hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, (const float*)dy, w_dgrad, (float*)dx,
                        d->Di, d->Hi, d->Wi, pz, py, px);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
   if (p.dgrad_zero_fill) {  // strided 1^3 convolution: only every second voxel per axis receives a contribution
-    const size_t nb = sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin;
+    const size_t nb = esz * (size_t)d->B * d->Di * d->Hi * d->Wi * d->Cin;
     if (addend == dx) {}  // in place: the untouched voxels already hold the other contribution
     else if (addend) HP_CHECK_HIP(hipMemcpyAsync(dx, addend, nb, hipMemcpyDeviceToDevice, st));
     else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
@@ -1644,28 +1756,33 @@ extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float
   return HP_OK;
 }
 
-extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float* dy, float* dw_packed,
+extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, const void* dy, float* dw_packed,
                                          void* stream) {
   HP_REQUIRE(d && x && dy && dw_packed, "hp_conv3d_backward_weight: null argument");
   ConvPlan p;
   int rc = make_plan(*d, p);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const int xh = (d->io & HP_IO_X_BF16) ? 1 : 0, dyh = (d->io & HP_IO_DY_BF16) ? 1 : 0;
+  HP_REQUIRE(!(p.stem && xh), "hp_conv3d_backward_weight: the stem reads its single-channel input as fp32");
+  p.wgrad.xh = xh;
+  p.wgrad.yh = dyh;  // element type of dY
   const IgemmGeom& g = p.wgrad;
   const int Kc = p.stem ? g.kpt * BK : g.Cin;
   HP_CHECK_HIP(hipMemsetAsync(dw_packed, 0, sizeof(float) * hp_conv3d_packed_weight_elems(d), st));
-  if (p.stem && p.planes == 0 && d->Cout == 64) {
+  if (p.stem && p.planes == 0 && d->Cout == 64 && !dyh) {
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     const long tiles = (long)d->B * pz * py * px;
     const int per_wg = (int)std::max<long>(1, (tiles + 1023) / 1024);  // ~1024 workgroups, 2 resident per CU
     HP_PROF("conv_wgrad", st);
-    hipLaunchKernelGGL(k_stem_wgrad_full, dim3((unsigned)((tiles + per_wg - 1) / per_wg)), dim3(256), 0, st, x, dy, dw_packed, d->Di,
+    hipLaunchKernelGGL(k_stem_wgrad_full, dim3((unsigned)((tiles + per_wg - 1) / per_wg)), dim3(256), 0, st, (const float*)x,
+                       (const float*)dy, dw_packed, d->Di,
                        d->Hi, d->Wi, pz, py, px, tiles, per_wg, Kc);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
   // dense 1^3 convolution with a 64-channel side and a 256-multiple side: one block per voxel split holds TN x TC
-  if (!p.stem && p.planes == 0 && g.mode == MODE_CONV && g.k == 1 && g.s == 1 && g.os == 1 && g.M >= (1l << 16)) {
+  if (!p.stem && p.planes == 0 && !xh && !dyh && g.mode == MODE_CONV && g.k == 1 && g.s == 1 && g.os == 1 && g.M >= (1l << 16)) {
     const bool wide_n = g.Nout % 256 == 0 && g.Cin == 64, wide_c = g.Nout == 64 && g.Cin % 256 == 0;
     if (wide_n || wide_c) {
       const int tiles = wide_n ? g.Nout / 256 : g.Cin / 256;
@@ -1674,10 +1791,10 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
       ms = std::max<long>(8, ms / 8 * 8);  // a multiple of 8 keeps the XCD renumbering on
       HP_PROF("conv_wgrad", st);
       if (wide_n)
-        hipLaunchKernelGGL((k_wgrad_dense<256, 64>), dim3((unsigned)(tiles * ms)), dim3(CT), 0, st, x, dy, dw_packed, g.M, g.Nout,
+        hipLaunchKernelGGL((k_wgrad_dense<256, 64>), dim3((unsigned)(tiles * ms)), dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g.M, g.Nout,
                            g.Cin, (int)ms, 1);
       else
-        hipLaunchKernelGGL((k_wgrad_dense<64, 256>), dim3((unsigned)(tiles * ms)), dim3(CT), 0, st, x, dy, dw_packed, g.M, g.Nout,
+        hipLaunchKernelGGL((k_wgrad_dense<64, 256>), dim3((unsigned)(tiles * ms)), dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g.M, g.Nout,
                            g.Cin, (int)ms, tiles);
       HP_CHECK_HIP(hipGetLastError());
       return HP_OK;
@@ -1699,8 +1816,15 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
 #define HP_WGRAD_P(STEM_, TT_, NTAP_, NP_)                                                                   \
   hipLaunchKernelGGL((k_wgrad<STEM_, TT_, NTAP_, NP_>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, \
                      (int)msplit, tiles_total, tap_groups)
+#define HP_WGRAD_XH(TT_, NTAP_)                                                                                   \
+  hipLaunchKernelGGL((k_wgrad<false, TT_, NTAP_, 1, true>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, \
+                     (int)msplit, tiles_total, tap_groups)
 #define HP_WGRAD(STEM_, TT_, NTAP_)                                                                                   \
   do {                                                                                                               \
+    if (!STEM_ && p.planes == 1 && xh && dyh && g.Cin % 8 == 0 && g.Nout % 8 == 0) {                                 \
+      HP_WGRAD_XH(TT_, NTAP_);                                                                                       \
+      break;                                                                                                         \
+    }                                                                                                                \
     switch (p.planes) {                                                                                              \
       case 1: HP_WGRAD_P(STEM_, TT_, NTAP_, 1); break;                                                               \
       case 2: HP_WGRAD_P(STEM_, TT_, NTAP_, 2); break;                                                               \
@@ -1713,6 +1837,7 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, 
     else if (multitap) HP_WGRAD(false, 64, 4);
     else HP_WGRAD(false, 64, 1);
 #undef HP_WGRAD
+#undef HP_WGRAD_XH
 #undef HP_WGRAD_P
   }
   HP_CHECK_HIP(hipGetLastError());

@@ -346,12 +346,12 @@ __global__ __launch_bounds__(MT) void k_depth_top4(const float* __restrict__ x, 
         else { v3 = v; i3 = d; }
       }
     }
-    const float inv = 1.0f / (float)(D - 1);
+    const float dm = (float)(D - 1);  // IEEE division, as the reference's (depdim - 1 - idx) / (depdim - 1)
     float* vo = vals + pl * 4 * HW + px;
     float* dq = dep + pl * 4 * HW + px;
     vo[0] = v0; vo[HW] = v1; vo[2 * HW] = v2; vo[3 * HW] = v3;
-    dq[0] = (float)(D - 1 - i0) * inv; dq[HW] = (float)(D - 1 - i1) * inv;
-    dq[2 * HW] = (float)(D - 1 - i2) * inv; dq[3 * HW] = (float)(D - 1 - i3) * inv;
+    dq[0] = __fdiv_rn((float)(D - 1 - i0), dm); dq[HW] = __fdiv_rn((float)(D - 1 - i1), dm);
+    dq[2 * HW] = __fdiv_rn((float)(D - 1 - i2), dm); dq[3 * HW] = __fdiv_rn((float)(D - 1 - i3), dm);
   }
 }
 

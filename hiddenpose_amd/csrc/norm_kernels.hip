@@ -40,8 +40,8 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 }
 
 // y = act((z - mean) * rstd * gamma + beta [+ res])
-__global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, const float4* __restrict__ res,
-                                                 float4* __restrict__ y, long n4, int C4, const float4* __restrict__ mean,
+__global__ __launch_bounds__(ET) void k_bn_apply(const void* __restrict__ z, int z_half, const void* __restrict__ res, int res_half,
+                                                 void* __restrict__ y, int y_half, long n4, int C4, const float4* __restrict__ mean,
                                                  const float4* __restrict__ rstd, const float4* __restrict__ gamma,
                                                  const float4* __restrict__ beta, int relu,
                                                  unsigned char* __restrict__ mask_out, const float4* __restrict__ rmean,
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
                                                  const float4* __restrict__ rbeta) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
-    const float4 v = z[i], m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+    const float4 v = hp_ld4(z, 4 * i, z_half), m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
     // y = z * sc + sh with sc = rstd * gamma, sh = beta - mean * sc: the backward rebuilds the ReLU mask with
     // exactly this expression
     const float4 sc = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
     o.z = fmaf(v.z, sc.z, sh.z);
     o.w = fmaf(v.w, sc.w, sh.w);
     if (res) {
-      float4 q = res[i];
+      float4 q = hp_ld4(res, 4 * i, res_half);
       if (rmean) {  // the residual is a raw convolution output with a BatchNorm of its own still to be applied
         const float4 m2 = rmean[c], r2 = rrstd[c], g2 = rgamma[c], b2 = rbeta[c];
         const float4 sc2 = make_float4(r2.x * g2.x, r2.y * g2.y, r2.z * g2.z, r2.w * g2.w);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
       o.z = fmaxf(o.z, 0.f);
       o.w = fmaxf(o.w, 0.f);
     }
-    y[i] = o;
+    hp_st4(y, 4 * i, o, y_half);
     // one byte per channel quad: which outputs are positive (the backward reads this instead of y: 1 B, not 16)
     if (mask_out)
       mask_out[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
@@ -88,8 +88,9 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const float4* __restrict__ z, c
 // Pass 1 of the backward: g = dy * [y > 0] (written to g_out), per channel sum(g) and
 // sum(g * zhat) into red[0:C], red[C:2C] (fp64).  Thread t owns channel quad (t % C4) --
 // the block strides over rows so that a thread always sees the same channels.
-__global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__ dy, const float4* __restrict__ y,
-                                                      const float4* __restrict__ z, float4* __restrict__ g_out, long M,
+template <int UNR>
+__global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const void* __restrict__ dy, int dy_half, const float4* __restrict__ y,
+                                                      const void* __restrict__ z, int z_half, void* __restrict__ g_out, int g_half, long M,
                                                       int C4, const float4* __restrict__ mean,
                                                       const float4* __restrict__ rstd, int relu,
                                                       double* __restrict__ red, const float4* __restrict__ gamma,
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
       }
       // UNR rows per trip: all their loads are issued before the first use (the pass is a pure read stream and
       // needs ~15 MB in flight chip-wide to run at HBM speed; one row per trip keeps ~6 MB in flight)
-      constexpr int UNR = 4;
+      // (bf16 tensors: 8 rows per trip, the same bytes in flight as 4 rows of fp32)
       const long stride = (long)gridDim.x * rows_per_pass;
       for (long row0 = (long)blockIdx.x * rows_per_pass + my_row; row0 < M; row0 += UNR * stride) {
         float4 gq[UNR], vq[UNR], yq[UNR];
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
           const long row = row0 + u * stride;
           okq[u] = row < M;
           const long i = (okq[u] ? row : row0) * C4 + cq;
-          gq[u] = dy[i];
-          vq[u] = z[i];
+          gq[u] = hp_ld4(dy, 4 * i, dy_half);
+          vq[u] = hp_ld4(z, 4 * i, z_half);
           mq[u] = (relu && mask) ? mask[i] : 0u;
           yq[u] = (relu && !mask && y) ? y[i] : make_float4(0, 0, 0, 0);
         }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const float4* __restrict__
             g.z = yy.z > 0.f ? g.z : 0.f;
             g.w = yy.w > 0.f ? g.w : 0.f;
           }
-          if (g_out) g_out[i] = g;
+          if (g_out) hp_st4(g_out, 4 * i, g, g_half);
           s.x += g.x;
           s.y += g.y;
           s.z += g.z;
@@ -210,34 +211,34 @@ __global__ void k_bn_bwd_coef(const double* __restrict__ red, long M, int C, con
   }
 }
 
-__global__ __launch_bounds__(ET) void k_bn_bwd_apply(const float4* __restrict__ g, const float4* __restrict__ z,
-                                                     float4* __restrict__ dz, long n4, int C4,
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply(const void* __restrict__ g, int g_half, const void* __restrict__ z, int z_half,
+                                                     void* __restrict__ dz, int dz_half, long n4, int C4,
                                                      const float4* __restrict__ ca, const float4* __restrict__ cb,
                                                      const float4* __restrict__ cc) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
-    const float4 gg = g[i], v = z[i], a = ca[c], b = cb[c], k = cc[c];
+    const float4 gg = hp_ld4(g, 4 * i, g_half), v = hp_ld4(z, 4 * i, z_half), a = ca[c], b = cb[c], k = cc[c];
     float4 o;
     o.x = a.x * gg.x + b.x * v.x + k.x;
     o.y = a.y * gg.y + b.y * v.y + k.y;
     o.z = a.z * gg.z + b.z * v.z + k.z;
     o.w = a.w * gg.w + b.w * v.w + k.w;
-    dz[i] = o;
+    hp_st4(dz, 4 * i, o, dz_half);
   }
 }
 
 // Pass 2 for units without a residual: the masked gradient is not parked in memory by pass 1; the ReLU mask is
 // rebuilt here from z (the same affine map, bit for bit), so the unit's backward moves 5 tensors instead of 6.
-__global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const float4* __restrict__ dy, const float4* __restrict__ z,
-                                                          float4* __restrict__ dz, long n4, int C4,
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const void* __restrict__ dy, int dy_half, const void* __restrict__ z, int z_half,
+                                                          void* __restrict__ dz, int dz_half, long n4, int C4,
                                                           const float4* __restrict__ ca, const float4* __restrict__ cb,
                                                           const float4* __restrict__ cc, const float4* __restrict__ mean,
                                                           const float4* __restrict__ rstd, const float4* __restrict__ gamma,
                                                           const float4* __restrict__ beta, int relu) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
-    float4 gg = dy[i];
-    const float4 v = z[i], a = ca[c], b = cb[c], k = cc[c];
+    float4 gg = hp_ld4(dy, 4 * i, dy_half);
+    const float4 v = hp_ld4(z, 4 * i, z_half), a = ca[c], b = cb[c], k = cc[c];
     if (relu) {
       const float4 m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
       const float4 sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
@@ -252,23 +253,23 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const float4* __restri
     o.y = a.y * gg.y + b.y * v.y + k.y;
     o.z = a.z * gg.z + b.z * v.z + k.z;
     o.w = a.w * gg.w + b.w * v.w + k.w;
-    dz[i] = o;
+    hp_st4(dz, 4 * i, o, dz_half);
   }
 }
 
 // Pass 2 for units whose ReLU mask is the byte mask of the forward apply (units with a residual, or a shortcut unit
 // fed by such a unit's output gradient): g = dy (.) mask is rebuilt from the byte instead of being parked by pass 1,
 // so neither this unit nor the consumer of the shortcut gradient moves a masked copy of dy through memory.
-__global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const float4* __restrict__ dy, const float4* __restrict__ z,
-                                                              float4* __restrict__ dz, long n4, int C4,
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const void* __restrict__ dy, int dy_half, const void* __restrict__ z, int z_half,
+                                                              void* __restrict__ dz, int dz_half, long n4, int C4,
                                                               const float4* __restrict__ ca, const float4* __restrict__ cb,
                                                               const float4* __restrict__ cc,
                                                               const unsigned char* __restrict__ mask) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
-    float4 gg = dy[i];
+    float4 gg = hp_ld4(dy, 4 * i, dy_half);
     const unsigned mk = mask[i];
-    const float4 v = z[i], a = ca[c], b = cb[c], k = cc[c];
+    const float4 v = hp_ld4(z, 4 * i, z_half), a = ca[c], b = cb[c], k = cc[c];
     gg.x = (mk & 1u) ? gg.x : 0.f;
     gg.y = (mk & 2u) ? gg.y : 0.f;
     gg.z = (mk & 4u) ? gg.z : 0.f;
@@ -278,15 +279,15 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const float4* __re
     o.y = a.y * gg.y + b.y * v.y + k.y;
     o.z = a.z * gg.z + b.z * v.z + k.z;
     o.w = a.w * gg.w + b.w * v.w + k.w;
-    dz[i] = o;
+    hp_st4(dz, 4 * i, o, dz_half);
   }
 }
 
 // ---- Two BatchNorm units that receive the same gradient g = dy (.) mask (Bottleneck with a shortcut convolution:
 // bn3 of the main branch and the shortcut's BatchNorm both feed the residual sum): one reduction and one apply pass
 // read dy and the byte mask once for both.  C4 <= ET is required (channel quads per row fit a workgroup pass).
-__global__ __launch_bounds__(ET) void k_bn_bwd_reduce_dual(const float4* __restrict__ dy, const unsigned char* __restrict__ mask,
-                                                           const float4* __restrict__ za, const float4* __restrict__ zb, long M,
+__global__ __launch_bounds__(ET) void k_bn_bwd_reduce_dual(const void* __restrict__ dy, int dy_half, const unsigned char* __restrict__ mask,
+                                                           const void* __restrict__ za, const void* __restrict__ zb, int z_half, long M,
                                                            int C4, const float4* __restrict__ mean_a,
                                                            const float4* __restrict__ rstd_a, const float4* __restrict__ mean_b,
                                                            const float4* __restrict__ rstd_b, double* __restrict__ red_a,
@@ -300,9 +301,9 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce_dual(const float4* __restr
     const float4 ma = mean_a[cq], ra = rstd_a[cq], mb = mean_b[cq], rb = rstd_b[cq];
     for (long row = (long)blockIdx.x * rows_per_pass + my_row; row < M; row += (long)gridDim.x * rows_per_pass) {
       const long i = row * C4 + cq;
-      float4 g = dy[i];
+      float4 g = hp_ld4(dy, 4 * i, dy_half);
       const unsigned mk = mask[i];
-      const float4 va = za[i], vb = zb[i];
+      const float4 va = hp_ld4(za, 4 * i, z_half), vb = hp_ld4(zb, 4 * i, z_half);
       g.x = (mk & 1u) ? g.x : 0.f;
       g.y = (mk & 2u) ? g.y : 0.f;
       g.z = (mk & 4u) ? g.z : 0.f;
@@ -341,30 +342,30 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_reduce_dual(const float4* __restr
   }
 }
 
-__global__ __launch_bounds__(ET) void k_bn_bwd_apply_dual(const float4* __restrict__ dy, const unsigned char* __restrict__ mask,
-                                                          const float4* __restrict__ za, const float4* __restrict__ zb,
-                                                          float4* __restrict__ dza, float4* __restrict__ dzb, long n4, int C4,
+__global__ __launch_bounds__(ET) void k_bn_bwd_apply_dual(const void* __restrict__ dy, int dy_half, const unsigned char* __restrict__ mask,
+                                                          const void* __restrict__ za, const void* __restrict__ zb, int z_half,
+                                                          void* __restrict__ dza, void* __restrict__ dzb, int dz_half, long n4, int C4,
                                                           const float4* __restrict__ caa, const float4* __restrict__ cba,
                                                           const float4* __restrict__ cca, const float4* __restrict__ cab,
                                                           const float4* __restrict__ cbb, const float4* __restrict__ ccb) {
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
     const int c = (int)(i % C4);
-    float4 gg = dy[i];
+    float4 gg = hp_ld4(dy, 4 * i, dy_half);
     const unsigned mk = mask[i];
-    const float4 va = za[i], vb = zb[i];
+    const float4 va = hp_ld4(za, 4 * i, z_half), vb = hp_ld4(zb, 4 * i, z_half);
     gg.x = (mk & 1u) ? gg.x : 0.f;
     gg.y = (mk & 2u) ? gg.y : 0.f;
     gg.z = (mk & 4u) ? gg.z : 0.f;
     gg.w = (mk & 8u) ? gg.w : 0.f;
     {
       const float4 a = caa[c], b = cba[c], k = cca[c];
-      dza[i] = make_float4(a.x * gg.x + b.x * va.x + k.x, a.y * gg.y + b.y * va.y + k.y, a.z * gg.z + b.z * va.z + k.z,
-                           a.w * gg.w + b.w * va.w + k.w);
+      hp_st4(dza, 4 * i, make_float4(a.x * gg.x + b.x * va.x + k.x, a.y * gg.y + b.y * va.y + k.y, a.z * gg.z + b.z * va.z + k.z,
+                                     a.w * gg.w + b.w * va.w + k.w), dz_half);
     }
     {
       const float4 a = cab[c], b = cbb[c], k = ccb[c];
-      dzb[i] = make_float4(a.x * gg.x + b.x * vb.x + k.x, a.y * gg.y + b.y * vb.y + k.y, a.z * gg.z + b.z * vb.z + k.z,
-                           a.w * gg.w + b.w * vb.w + k.w);
+      hp_st4(dzb, 4 * i, make_float4(a.x * gg.x + b.x * vb.x + k.x, a.y * gg.y + b.y * vb.y + k.y, a.z * gg.z + b.z * vb.z + k.z,
+                                     a.w * gg.w + b.w * vb.w + k.w), dz_half);
     }
   }
 }
@@ -782,6 +783,10 @@ __global__ void k_transpose_vc(const float* __restrict__ in, float* __restrict__
   }
 }
 
+__global__ __launch_bounds__(ET) void k_cast(const void* __restrict__ x, int x_half, void* __restrict__ y, int y_half, long n4) {
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) hp_st4(y, 4 * i, hp_ld4(x, 4 * i, x_half), y_half);
+}
+
 static unsigned grid_for(long n, int per_block = ET) {
   return (unsigned)std::min<long>((n + per_block - 1) / per_block, 256 * 8);
 }
@@ -814,21 +819,24 @@ extern "C" int hp_bn_eval_stats(const float* running_mean, const float* running_
   return HP_OK;
 }
 
-extern "C" int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream) {
-  return hp_bn_apply_res_bn(z, res, y, M, C, mean, rstd, gamma, beta, relu, relu_mask, nullptr, nullptr, nullptr, nullptr, stream);
+extern "C" int hp_bn_apply(const void* z, const void* res, void* y, long M, int C, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int relu, unsigned char* relu_mask, int io, void* stream) {
+  return hp_bn_apply_res_bn(z, res, y, M, C, mean, rstd, gamma, beta, relu, relu_mask, nullptr, nullptr, nullptr, nullptr, io, stream);
 }
 
-extern "C" int hp_bn_apply_res_bn(const float* z, const float* res, float* y, long M, int C, const float* mean,
+extern "C" int hp_bn_apply_res_bn(const void* z, const void* res, void* y, long M, int C, const float* mean,
                                   const float* rstd, const float* gamma, const float* beta, int relu, unsigned char* relu_mask,
                                   const float* res_mean, const float* res_rstd, const float* res_gamma, const float* res_beta,
-                                  void* stream) {
+                                  int io, void* stream) {
   HP_REQUIRE(z && y && mean && rstd && gamma && beta && M > 0 && C > 0 && C % 4 == 0, "hp_bn_apply: bad argument");
   HP_REQUIRE(!res_mean || (res && res_rstd && res_gamma && res_beta), "hp_bn_apply_res_bn: incomplete residual BatchNorm");
   const long n4 = M * (C / 4);
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("bn_apply", st);
-  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)z, (const float4*)res, (float4*)y, n4,
+  // io & HP_BN_ACT_BF16: y (and a plain residual, which is an activation too) are bf16; a residual that comes with its own
+  // BatchNorm is the shortcut convolution's raw fp32 output
+  const int act_half = (io & HP_BN_ACT_BF16) ? 1 : 0, z_half = (io & HP_BN_Z_BF16) ? 1 : 0;
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n4)), dim3(ET), 0, st, z, z_half, res, res_mean ? z_half : act_half, y, act_half, n4,
                      C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu, relu_mask,
                      (const float4*)res_mean, (const float4*)res_rstd, (const float4*)res_gamma, (const float4*)res_beta);
   HP_CHECK_HIP(hipGetLastError());
@@ -838,10 +846,11 @@ extern "C" int hp_bn_apply_res_bn(const float* z, const float* res, float* y, lo
 // workspace: 2*C doubles (reduction) + 3*C floats (coefficients)
 extern "C" size_t hp_bn_backward_workspace_bytes(int C) { return sizeof(double) * 2 * C + sizeof(float) * 3 * C; }
 
-extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
+extern "C" int hp_bn_backward(const void* dy, const float* y, const void* z, void* g_out, void* dz, long M, int C,
                               const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask,
                               int relu, int train, float* dgamma, float* dbeta, const unsigned char* relu_mask,
-                              void* workspace, void* stream) {
+                              void* workspace, int io, void* stream) {
+  const int dy_half = (io & HP_BN_DY_BF16) ? 1 : 0, dz_half = (io & HP_BN_DZ_BF16) ? 1 : 0, z_half = (io & HP_BN_Z_BF16) ? 1 : 0;
   HP_REQUIRE(dy && z && dz && mean && rstd && gamma && workspace && M > 0 && C > 0 && C % 4 == 0,
              "hp_bn_backward: bad argument");
   HP_REQUIRE(!relu || y || relu_mask || beta_for_mask,
@@ -859,13 +868,14 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
   const bool remask = !g_out && !y && !relu_mask && dy != dz;
   // byte mask given and nobody wants g: pass 2 re-applies the byte mask to dy (nothing parked)
   const bool bytemask = relu && relu_mask && !g_out && !y;
-  float* gbuf = (remask || bytemask) ? nullptr : g_out ? g_out : dz;
+  void* gbuf = (remask || bytemask) ? nullptr : g_out ? g_out : dz;
   {
     HP_PROF("bn_bwd_reduce", st);
     const int rows_per_pass = C4 < ET ? ET / C4 : 1;
     const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(ET), 0, st, (const float4*)dy, (const float4*)y, (const float4*)z,
-                       (float4*)gbuf, M, C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma,
+    auto* const kern = (dy_half && z_half) ? k_bn_bwd_reduce<8> : k_bn_bwd_reduce<4>;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half,
+                       gbuf, dz_half, M, C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma,
                        (const float4*)beta_for_mask, relu_mask);
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, M, C, mean, rstd, gamma, train, dgamma,
@@ -874,25 +884,26 @@ extern "C" int hp_bn_backward(const float* dy, const float* y, const float* z, f
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
     if (bytemask)
-      hipLaunchKernelGGL(k_bn_bwd_apply_bytemask, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, (const float4*)z,
-                         (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
+      hipLaunchKernelGGL(k_bn_bwd_apply_bytemask, dim3(grid_for(n4)), dim3(ET), 0, st, dy, dy_half, z, z_half,
+                         dz, dz_half, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
     else if (remask)
-      hipLaunchKernelGGL(k_bn_bwd_apply_mask, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, (const float4*)z,
-                         (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean,
+      hipLaunchKernelGGL(k_bn_bwd_apply_mask, dim3(grid_for(n4)), dim3(ET), 0, st, dy, dy_half, z, z_half,
+                         dz, dz_half, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean,
                          (const float4*)rstd, (const float4*)gamma, (const float4*)beta_for_mask, relu);
     else
-      hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)gbuf, (const float4*)z,
-                         (float4*)dz, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
+      hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, gbuf, dz_half, z, z_half,
+                         dz, dz_half, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
 
-extern "C" int hp_bn_backward_dual(const float* dy, const unsigned char* relu_mask, long M, int C, const float* z_a,
-                                   float* dz_a, const float* mean_a, const float* rstd_a, const float* gamma_a, int train_a,
-                                   float* dgamma_a, float* dbeta_a, const float* z_b, float* dz_b, const float* mean_b,
+extern "C" int hp_bn_backward_dual(const void* dy, const unsigned char* relu_mask, long M, int C, const void* z_a,
+                                   void* dz_a, const float* mean_a, const float* rstd_a, const float* gamma_a, int train_a,
+                                   float* dgamma_a, float* dbeta_a, const void* z_b, void* dz_b, const float* mean_b,
                                    const float* rstd_b, const float* gamma_b, int train_b, float* dgamma_b, float* dbeta_b,
-                                   void* workspace, void* stream) {
+                                   void* workspace, int io, void* stream) {
+  const int dy_half = (io & HP_BN_DY_BF16) ? 1 : 0, dz_half = (io & HP_BN_DZ_BF16) ? 1 : 0, z_half = (io & HP_BN_Z_BF16) ? 1 : 0;
   HP_REQUIRE(dy && relu_mask && z_a && dz_a && mean_a && rstd_a && gamma_a && z_b && dz_b && mean_b && rstd_b && gamma_b &&
                  workspace && M > 0 && C > 0 && C % 4 == 0 && C / 4 <= ET,
              "hp_bn_backward_dual: bad argument (C must be a multiple of 4, at most %d)", 4 * ET);
@@ -909,8 +920,7 @@ extern "C" int hp_bn_backward_dual(const float* dy, const unsigned char* relu_ma
     HP_PROF("bn_bwd_reduce", st);
     const int rows_per_pass = ET / C4;
     const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
-    hipLaunchKernelGGL(k_bn_bwd_reduce_dual, dim3(nb), dim3(ET), 0, st, (const float4*)dy, relu_mask, (const float4*)z_a,
-                       (const float4*)z_b, M, C4, (const float4*)mean_a, (const float4*)rstd_a, (const float4*)mean_b,
+    hipLaunchKernelGGL(k_bn_bwd_reduce_dual, dim3(nb), dim3(ET), 0, st, dy, dy_half, relu_mask, z_a, z_b, z_half, M, C4, (const float4*)mean_a, (const float4*)rstd_a, (const float4*)mean_b,
                        (const float4*)rstd_b, red_a, red_b);
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red_a, M, C, mean_a, rstd_a, gamma_a, train_a,
@@ -920,8 +930,8 @@ extern "C" int hp_bn_backward_dual(const float* dy, const unsigned char* relu_ma
   {
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
-    hipLaunchKernelGGL(k_bn_bwd_apply_dual, dim3(grid_for(n4)), dim3(ET), 0, st, (const float4*)dy, relu_mask, (const float4*)z_a,
-                       (const float4*)z_b, (float4*)dz_a, (float4*)dz_b, n4, C4, (const float4*)ca_a, (const float4*)cb_a,
+    hipLaunchKernelGGL(k_bn_bwd_apply_dual, dim3(grid_for(n4)), dim3(ET), 0, st, dy, dy_half, relu_mask, z_a, z_b, z_half,
+                       dz_a, dz_b, dz_half, n4, C4, (const float4*)ca_a, (const float4*)cb_a,
                        (const float4*)cc_a, (const float4*)ca_b, (const float4*)cb_b, (const float4*)cc_b);
   }
   HP_CHECK_HIP(hipGetLastError());
@@ -1027,6 +1037,24 @@ extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled
                        (const float4*)dpooled, (float4*)dz, B, D, H, W, C4, (const float4*)sc, (const float4*)sh, (const float4*)ca,
                        (const float4*)cb, (const float4*)cc, make_decode(D, H, W), is_pow2(C4) ? ilog2(C4) : -1);
   }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+  HP_REQUIRE(x && y && n > 0 && n % 4 == 0, "hp_cast_f32_to_bf16: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("cast_bf16", st);
+  hipLaunchKernelGGL(k_cast, dim3(grid_for(n / 4)), dim3(ET), 0, st, (const void*)x, 0, y, 1, n / 4);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_cast_bf16_to_f32(const void* x, float* y, long n, void* stream) {
+  HP_REQUIRE(x && y && n > 0 && n % 4 == 0, "hp_cast_bf16_to_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("cast_bf16", st);
+  hipLaunchKernelGGL(k_cast, dim3(grid_for(n / 4)), dim3(ET), 0, st, x, 1, (void*)y, 0, n / 4);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

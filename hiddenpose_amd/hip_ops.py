@@ -395,8 +395,21 @@ def upsample_cat(x1, skip):
 # ---------------------------------------------------------------- posenet3d_50 (rows P1-P3)
 # Channels-last (B, D, H, W, C) fp32 tensors between units; every kernel is in libhiddenpose_hip.so
 # (csrc/conv_kernels.hip: exact-fp32 MFMA implicit GEMM; csrc/norm_kernels.hip: BN / pool / layout).
-_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}  # HP_PRECISION_* of include/hiddenpose_hip.h
+_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "bf16s": 1}  # HP_PRECISION_* of include/hiddenpose_hip.h
 _conv_precision = 0
+_conv_precision_name = "fp32"
+# "bf16s" = BASELINE configs[2] in full: bf16 matrix cores AND bf16 activation storage -- every tensor that crosses an
+# autograd-node boundary inside the regressor (unit outputs y, their gradients) and the gradients handed from BatchNorm
+# to the convolution gradients (dz) are bf16 in HBM; raw convolution outputs z, statistics, weights, weight
+# gradients and everything outside the regressor stay fp32.  ("bf16": bf16 matrix cores over fp32 tensors.)
+_act_bf16 = False
+_BF = torch.bfloat16
+HP_IO_X, HP_IO_Y, HP_IO_DY, HP_IO_DX = 1, 2, 4, 8         # hp_conv_desc.io
+HP_BN_ACT, HP_BN_DY, HP_BN_DZ, HP_BN_Z = 1, 2, 4, 8        # `io` of the hp_bn_* calls
+
+
+def _h(t) -> bool:
+    return t is not None and t.dtype == _BF
 
 
 def set_conv_precision(name: str) -> str:
@@ -407,13 +420,16 @@ def set_conv_precision(name: str) -> str:
     global _conv_precision
     if name not in _PRECISIONS:
         raise ValueError(f"conv precision must be one of {sorted(_PRECISIONS)}, got {name!r}")
+    global _conv_precision_name, _act_bf16
     prev = get_conv_precision()
     _conv_precision = _PRECISIONS[name]
+    _conv_precision_name = name
+    _act_bf16 = name == "bf16s"
     return prev
 
 
 def get_conv_precision() -> str:
-    return next(k for k, v in _PRECISIONS.items() if v == _conv_precision)
+    return _conv_precision_name
 
 
 def _desc(x_cl, cout, k, stride, pad, transposed):
@@ -434,21 +450,37 @@ def _same_as_packed(desc):
     return desc.k == 1 and not desc.transposed
 
 
-def _pack(desc, w, want_fwd, want_dgrad):
+HP_IO_W = 16
+
+
+def _w_half(desc, gathered_is_bf16: bool, gathered_channels: int) -> bool:
+    """bf16 packed weights: the bf16-storage tiles of the implicit GEMM (bf16 gathered tensor, single-plane bf16
+    arithmetic, its channel count a multiple of 64, not the stem)."""
+    return gathered_is_bf16 and desc.precision == 1 and gathered_channels % 64 == 0 and not (desc.Cin == 1 and desc.k == 7)
+
+
+def _pack(desc, w, want_fwd, want_dgrad, half=False):
+    """Packed weight images of hp_conv3d_pack_weight: (w_fwd, w_dgrad); `half`: as bf16 (see _w_half)."""
     L = _lib.lib()
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
-    if want_fwd and _same_as_packed(desc) and w.is_contiguous():
-        wf, want_fwd = w.detach().reshape(-1), False
-        if not want_dgrad:
-            return wf, None
-        wd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
-        _lib.check(L.hp_conv3d_pack_weight(_C.byref(desc), w.data_ptr(), None, wd.data_ptr(), _stream(w)), "hp_conv3d_pack_weight")
+    io0 = desc.io
+    desc.io = HP_IO_W if half else 0
+    try:
+        if want_fwd and not half and _same_as_packed(desc) and w.is_contiguous():
+            wf, want_fwd = w.detach().reshape(-1), False
+            if not want_dgrad:
+                return wf, None
+            wd = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+            _lib.check(L.hp_conv3d_pack_weight(_C.byref(desc), w.data_ptr(), None, wd.data_ptr(), _stream(w)), "hp_conv3d_pack_weight")
+            return wf, wd
+        dt = _BF if half else torch.float32
+        wf = torch.empty(n, dtype=dt, device=w.device) if want_fwd else None
+        wd = torch.empty(w.numel(), dtype=dt, device=w.device) if want_dgrad else None
+        _lib.check(L.hp_conv3d_pack_weight(_C.byref(desc), w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), _stream(w)),
+                   "hp_conv3d_pack_weight")
         return wf, wd
-    wf = torch.empty(n, dtype=torch.float32, device=w.device) if want_fwd else None
-    wd = torch.empty(w.numel(), dtype=torch.float32, device=w.device) if want_dgrad else None
-    _lib.check(L.hp_conv3d_pack_weight(_C.byref(desc), w.data_ptr(), _lib.ptr(wf), _lib.ptr(wd), _stream(w)),
-               "hp_conv3d_pack_weight")
-    return wf, wd
+    finally:
+        desc.io = io0
 
 
 class GradLink:
@@ -533,8 +565,13 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
     L = _lib.lib()
     st = _stream(x)
     dx = None
+    # element types of this call's activation tensors: x / dx follow x, dy follows dz (hp_conv_desc.io)
+    desc.io = (HP_IO_X | HP_IO_DX if _h(x) else 0) | (HP_IO_DY if _h(dz) else 0)
+    assert addend is None or addend.dtype == x.dtype
     if need_dx:
-        _, wd = _pack(desc, w, False, True)
+        wh = _w_half(desc, _h(dz), desc.Cout)   # the data gradient gathers dz: Cout channels
+        _, wd = _pack(desc, w, False, True, wh)
+        desc.io |= HP_IO_W if wh else 0
         # strided 1^3 convolution: its gradient reaches every second voxel per axis only, so it is added into the
         # addend's own buffer (no zero-filled tensor, no copy)
         inplace = addend is not None and addend_mask is None and desc.k == 1 and desc.stride == 2 and not desc.transposed
@@ -546,6 +583,7 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
         else:
             _lib.check(L.hp_conv3d_backward_data(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend), st),
                        "hp_conv3d_backward_data")
+    desc.io &= ~HP_IO_W
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
     side = _wgrad_side_stream(x.device)
     if side is None:
@@ -604,12 +642,15 @@ class _ConvBnAct(torch.autograd.Function):
         desc = _desc(x, cout, k, stride, pad, transposed)
         do, ho, wo = _out_dims(desc)
         st = _stream(x)
+        act = _act_bf16 or _h(x)   # bf16 activation storage: z, y (and dz, dx in the backward) are bf16; statistics fp32
         with torch.cuda.device(x.device):
-            wf, _ = _pack(desc, w, True, False)
-            z = torch.empty(desc.B, do, ho, wo, cout, dtype=torch.float32, device=x.device)
+            wh = _w_half(desc, _h(x), desc.Cin)
+            wf, _ = _pack(desc, w, True, False, wh)
+            z = torch.empty(desc.B, do, ho, wo, cout, dtype=_BF if act else torch.float32, device=x.device)
             M = z.numel() // cout
             train = bn.training
             stats = torch.empty(2 * cout, dtype=torch.float64, device=x.device) if train else None
+            desc.io = (HP_IO_X if _h(x) else 0) | (HP_IO_W if wh else 0) | (HP_IO_Y if act else 0)
             _lib.check(L.hp_conv3d_forward(_C.byref(desc), x.data_ptr(), wf.data_ptr(), None, z.data_ptr(),
                                            _lib.ptr(stats), st), "hp_conv3d_forward")
             mean = torch.empty(cout, dtype=torch.float32, device=x.device)
@@ -629,11 +670,14 @@ class _ConvBnAct(torch.autograd.Function):
                 res_link.short = (z.detach(), mean, rstd, gamma, train)   # an alias, not the output object: no ctx cycle
                 ctx.save_for_backward(x, w, gamma, beta, z, None, mean, rstd)
                 ctx.cfg = (desc, relu, train, False)
+                ctx.act = _act_bf16 or _h(x)
                 ctx.links = (link_in, link_out, res_link)
                 return z
-            y = torch.empty_like(z)
+            y = torch.empty_like(z, dtype=_BF if act else torch.float32)
+            bio = (HP_BN_ACT | HP_BN_Z) if act else 0
             if res is not None:
                 res = res.contiguous()
+                assert (res_link is not None and res_link.affine is not None) or _h(res) == act, "residual / output element types differ"
             # with a residual the backward needs the sign pattern of the output: a byte per channel quad, written here
             mask = (torch.empty(M * cout // 4, dtype=torch.uint8, device=x.device)
                     if (res is not None and relu and any(ctx.needs_input_grad)) else None)
@@ -643,13 +687,14 @@ class _ConvBnAct(torch.autograd.Function):
                 _lib.check(L.hp_bn_apply_res_bn(z.data_ptr(), res.data_ptr(), y.data_ptr(), M, cout, mean.data_ptr(),
                                                 rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
                                                 _lib.ptr(mask), raff[0].data_ptr(), raff[1].data_ptr(), raff[2].data_ptr(),
-                                                raff[3].data_ptr(), st), "hp_bn_apply_res_bn")
+                                                raff[3].data_ptr(), bio, st), "hp_bn_apply_res_bn")
             else:
                 _lib.check(L.hp_bn_apply(z.data_ptr(), _lib.ptr(res), y.data_ptr(), M, cout, mean.data_ptr(), rstd.data_ptr(),
-                                         gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, _lib.ptr(mask), st), "hp_bn_apply")
+                                         gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0, _lib.ptr(mask), bio, st), "hp_bn_apply")
         # without a residual the mask is rebuilt from z; y itself is kept only by the consumer that reads it as input
         ctx.save_for_backward(x, w, gamma, beta, z, mask, mean, rstd)
         ctx.cfg = (desc, relu, train, res is not None)
+        ctx.act = act
         ctx.links = (link_in, link_out, res_link)
         return y
 
@@ -668,7 +713,9 @@ class _ConvBnAct(torch.autograd.Function):
             # data gradient through link_out, or the shortcut unit through res_link) it takes dy and the byte mask
             # instead, and g is never written.
             deferred = has_res and mask is not None and (link_out is not None or res_link is not None)
-            g = torch.empty_like(z) if (has_res and not deferred) else None
+            hdt = _BF if ctx.act else torch.float32     # dz (to the convolution gradients) and g (to the residual input)
+            bio = (HP_BN_DY if _h(dy) else 0) | (HP_BN_DZ if ctx.act else 0) | (HP_BN_Z if _h(z) else 0)
+            g = torch.empty_like(z, dtype=hdt) if (has_res and not deferred) else None
             in_mask, relu_flag = mask, relu
             if res_link is not None and not has_res and res_link.mask is not None:
                 # shortcut unit (no ReLU of its own): the incoming dy still lacks the residual unit's output mask
@@ -681,22 +728,22 @@ class _ConvBnAct(torch.autograd.Function):
                 (dz, dgamma, dbeta), res_link.done = res_link.done, None
             elif deferred and res_link is not None and res_link.short is not None and cout <= 1024:
                 (zb, mb, rb, gb, trb), res_link.short = res_link.short, None
-                dz = torch.empty_like(z)
-                dzb, dgb, dbb = torch.empty_like(zb), torch.empty_like(gb), torch.empty_like(gb)
+                dz = torch.empty_like(z, dtype=hdt)
+                dzb, dgb, dbb = torch.empty_like(zb, dtype=hdt), torch.empty_like(gb), torch.empty_like(gb)
                 ws = torch.empty(2 * nws // 4 + 8, dtype=torch.float32, device=x.device)
                 _lib.check(L.hp_bn_backward_dual(dy.data_ptr(), mask.data_ptr(), M, cout, z.data_ptr(), dz.data_ptr(),
                                                  mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), 1 if train else 0,
                                                  dgamma.data_ptr(), dbeta.data_ptr(), zb.data_ptr(), dzb.data_ptr(), mb.data_ptr(),
                                                  rb.data_ptr(), gb.data_ptr(), 1 if trb else 0, dgb.data_ptr(), dbb.data_ptr(),
-                                                 ws.data_ptr(), st), "hp_bn_backward_dual")
+                                                 ws.data_ptr(), bio, st), "hp_bn_backward_dual")
                 res_link.done = (dzb, dgb, dbb)
             else:
-                dz = torch.empty_like(z)
+                dz = torch.empty_like(z, dtype=hdt)
                 ws = torch.empty(nws // 4 + 2, dtype=torch.float32, device=x.device)
                 _lib.check(L.hp_bn_backward(dy.data_ptr(), None, z.data_ptr(), _lib.ptr(g), dz.data_ptr(), M, cout,
                                             mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                             1 if relu_flag else 0, 1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(),
-                                            _lib.ptr(in_mask), ws.data_ptr(), st), "hp_bn_backward")
+                                            _lib.ptr(in_mask), ws.data_ptr(), bio, st), "hp_bn_backward")
             addend = addend_mask = None
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:
@@ -726,9 +773,11 @@ class _ConvBiasToNCDHW(torch.autograd.Function):
         desc = _desc(x, cout, 1, 1, 0, False)
         st = _stream(x)
         with torch.cuda.device(x.device):
-            wf, _ = _pack(desc, w, True, False)
+            wh = _w_half(desc, _h(x), desc.Cin)
+            wf, _ = _pack(desc, w, True, False, wh)
             b, d, h, wd_, _ = x.shape
             ycl = torch.empty(b, d, h, wd_, cout, dtype=torch.float32, device=x.device)
+            desc.io = (HP_IO_X if _h(x) else 0) | (HP_IO_W if wh else 0)
             _lib.check(L.hp_conv3d_forward(_C.byref(desc), x.data_ptr(), wf.data_ptr(), bias.data_ptr(), ycl.data_ptr(),
                                            None, st), "hp_conv3d_forward")
             y = torch.empty(b, cout, d, h, wd_, dtype=torch.float32, device=x.device)
@@ -824,9 +873,13 @@ class _StemConvBnReluPool(torch.autograd.Function):
             _lib.check(L.hp_stem_bn_relu_pool_forward(z.data_ptr(), pooled.data_ptr(), b, d, h, wd_, cout, mean.data_ptr(),
                                                       rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), st),
                        "hp_stem_bn_relu_pool_forward")
+            out = pooled
+            if _act_bf16:   # the fused stem kernels stay fp32 (its backward compares pooled values); the consumers get a bf16 copy
+                out = torch.empty_like(pooled, dtype=_BF)
+                _lib.check(L.hp_cast_f32_to_bf16(pooled.data_ptr(), out.data_ptr(), pooled.numel(), st), "hp_cast_f32_to_bf16")
         ctx.save_for_backward(x, w, gamma, beta, z, pooled, mean, rstd)
         ctx.cfg = (desc, train)
-        return pooled
+        return out
 
     @staticmethod
     def backward(ctx, dp):
@@ -837,6 +890,10 @@ class _StemConvBnReluPool(torch.autograd.Function):
         dp = dp.contiguous()
         st = _stream(x)
         with torch.cuda.device(x.device):
+            if _h(dp):
+                dpf = torch.empty_like(dp, dtype=torch.float32)
+                _lib.check(L.hp_cast_bf16_to_f32(dp.data_ptr(), dpf.data_ptr(), dp.numel(), st), "hp_cast_bf16_to_f32")
+                dp = dpf
             dz = torch.empty_like(z)
             dgamma = torch.empty_like(gamma)
             dbeta = torch.empty_like(gamma)

@@ -124,31 +124,45 @@ typedef struct hp_conv_desc {
   int k, stride, pad;
   int transposed; /* 0: Conv3d, 1: ConvTranspose3d */
   int precision;  /* HP_PRECISION_* */
+  int io;         /* HP_IO_*: which activation tensors of the call are bf16 instead of fp32 (0: all fp32) */
 } hp_conv_desc;
+/* Element type of the activation tensors (BASELINE configs[2]: bf16 storage, fp32 accumulators and statistics).
+ * Pointers of flagged tensors address 2-byte bf16 elements; weights, bias, statistics and dw stay fp32. */
+#define HP_IO_X_BF16 1  /* forward input x (also the X operand of the weight gradient) */
+#define HP_IO_Y_BF16 2  /* forward output y */
+#define HP_IO_DY_BF16 4 /* incoming gradient dy of the data / weight gradient */
+#define HP_IO_DX_BF16 8 /* data gradient dx and its addend */
+#define HP_IO_W_BF16 16 /* packed weight images (w_fwd / w_dgrad of hp_conv3d_pack_weight, as read by forward / backward_data)
+                         * are bf16: only with a bf16 gathered tensor, HP_PRECISION_BF16 and its channel count % 64 == 0 */
 
 size_t hp_conv3d_packed_weight_elems(const hp_conv_desc* d);
-int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, float* w_fwd, float* w_dgrad, void* stream);
+int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, void* w_fwd, void* w_dgrad, void* stream);
 int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_packed, float* dw_torch, void* stream);
 /* y = conv(x) [+ bias]; if stats != NULL it receives per-channel sum and sum of squares of y
  * (2*Cout doubles, zeroed by the call) for train-mode BatchNorm. */
-int hp_conv3d_forward(const hp_conv_desc* d, const float* x, const float* w_fwd, const float* bias, float* y,
+int hp_conv3d_forward(const hp_conv_desc* d, const void* x, const float* w_fwd, const float* bias, void* y,
                       double* stats, void* stream);
 /* dx = conv^T(dy) [+ addend]: `addend` (same shape as dx, may be NULL) lets a second gradient contribution to the
  * same tensor (residual / shortcut branch) be summed in the epilogue instead of by a separate pass.  For a strided
  * 1^3 convolution (gradient reaches every second voxel per axis) addend may BE dx: the sum is then formed in place
  * and no zero-filled or copied tensor is produced. */
-int hp_conv3d_backward_data(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                            const float* addend, void* stream);
+int hp_conv3d_backward_data(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx,
+                            const void* addend, void* stream);
 /* Same with the addend gated by a byte mask (hp_bn_apply's relu_mask layout: one byte per channel quad of dx):
  * dx = conv^T(dy) + addend (.) mask.  Bottleneck.forward's identity shortcut (posenet3d_50.py:90-93): the shortcut
  * gradient is the block's output gradient times the sign mask of the block output, which therefore is never
  * written as a tensor.  Dense (stride-1) data gradients with > 32 input channels, a multiple of 4, only. */
-int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                   const float* addend, const unsigned char* addend_mask, void* stream);
+int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx,
+                                   const void* addend, const unsigned char* addend_mask, void* stream);
 /* dw_packed (same layout as w_fwd) is zeroed and accumulated by the call. */
-int hp_conv3d_backward_weight(const hp_conv_desc* d, const float* x, const float* dy, float* dw_packed, void* stream);
+int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, const void* dy, float* dw_packed, void* stream);
 
-/* BatchNorm3d (posenet3d_50.py:70-95,133,182) on [M][C] channels-last matrices. */
+/* BatchNorm3d (posenet3d_50.py:70-95,133,182) on [M][C] channels-last matrices.  The raw convolution output z, the
+ * statistics and every parameter are fp32; `io` says which ACTIVATION tensors of a call are bf16 (0: all fp32): */
+#define HP_BN_ACT_BF16 1 /* forward: y, and a plain residual `res` */
+#define HP_BN_DY_BF16 2  /* backward: the incoming gradient dy */
+#define HP_BN_DZ_BF16 4  /* backward: the outgoing gradients dz (and g_out) */
+#define HP_BN_Z_BF16 8   /* the raw convolution output z (and, in hp_bn_apply_res_bn, the raw shortcut output) */
 int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float momentum, float* mean, float* rstd,
                          float* running_mean, float* running_var, void* stream);
 /* Same, and BatchNorm3d's `num_batches_tracked` (int64, device) is incremented by the same launch (may be NULL). */
@@ -159,15 +173,15 @@ int hp_bn_eval_stats(const float* running_mean, const float* running_var, int C,
 /* y = act((z - mean) * rstd * gamma + beta [+ res]);  res may be NULL; relu = 0|1.
  * relu_mask (may be NULL): M*C/4 bytes, bit k of byte q = [y[4q + k] > 0] -- what the backward of a unit WITH a
  * residual needs of y (1 byte instead of 16 per channel quad). */
-int hp_bn_apply(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
-                const float* gamma, const float* beta, int relu, unsigned char* relu_mask, void* stream);
+int hp_bn_apply(const void* z, const void* res, void* y, long M, int C, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, int relu, unsigned char* relu_mask, int io, void* stream);
 /* Same, with the residual given as the RAW output of the shortcut convolution and that shortcut's BatchNorm
  * (res_mean .. res_beta, all C) applied on the fly: y = act(BN(z) + BN_res(res)) -- Bottleneck.forward with a
  * `downsample` branch (posenet3d_50.py:86-93) without materialising the normalised shortcut tensor.  The result is
- * bit-identical to hp_bn_apply on a stored BN_res(res). */
-int hp_bn_apply_res_bn(const float* z, const float* res, float* y, long M, int C, const float* mean, const float* rstd,
+ * bit-identical to hp_bn_apply on a stored BN_res(res).  (res is that raw fp32 tensor whatever `io` says.) */
+int hp_bn_apply_res_bn(const void* z, const void* res, void* y, long M, int C, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, int relu, unsigned char* relu_mask, const float* res_mean,
-                       const float* res_rstd, const float* res_gamma, const float* res_beta, void* stream);
+                       const float* res_rstd, const float* res_gamma, const float* res_beta, int io, void* stream);
 size_t hp_bn_backward_workspace_bytes(int C);
 /* g = dy * [y > 0] (stored to g_out if not NULL: gradient of the residual branch);
  * dz = gradient w.r.t. the BatchNorm input; dgamma/dbeta may be NULL.
@@ -176,17 +190,23 @@ size_t hp_bn_backward_workspace_bytes(int C);
  * shortcut unit whose incoming gradient is that unit's masked output gradient. */
 /* The ReLU mask comes from relu_mask (hp_bn_apply's byte mask) if given, else from y, else -- unit without a
  * residual -- it is rebuilt from z and beta_for_mask. */
-int hp_bn_backward(const float* dy, const float* y, const float* z, float* g_out, float* dz, long M, int C,
+int hp_bn_backward(const void* dy, const float* y, const void* z, void* g_out, void* dz, long M, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta_for_mask, int relu,
-                   int train, float* dgamma, float* dbeta, const unsigned char* relu_mask, void* workspace, void* stream);
+                   int train, float* dgamma, float* dbeta, const unsigned char* relu_mask, void* workspace, int io,
+                   void* stream);
 /* Two BatchNorm units fed by the same gradient g = dy (.) relu_mask -- bn3 of the main branch (a) and the BatchNorm
  * of the shortcut convolution (b) of a Bottleneck with `downsample` (posenet3d_50.py:86-93): one reduction and one
  * apply pass serve both (dy and the mask are read once per pass instead of twice).  Same arithmetic per unit as
  * hp_bn_backward; C <= 1024.  workspace: 2 * (hp_bn_backward_workspace_bytes(C) rounded up to 16) bytes. */
-int hp_bn_backward_dual(const float* dy, const unsigned char* relu_mask, long M, int C, const float* z_a, float* dz_a,
+int hp_bn_backward_dual(const void* dy, const unsigned char* relu_mask, long M, int C, const void* z_a, void* dz_a,
                         const float* mean_a, const float* rstd_a, const float* gamma_a, int train_a, float* dgamma_a,
-                        float* dbeta_a, const float* z_b, float* dz_b, const float* mean_b, const float* rstd_b,
-                        const float* gamma_b, int train_b, float* dgamma_b, float* dbeta_b, void* workspace, void* stream);
+                        float* dbeta_a, const void* z_b, void* dz_b, const float* mean_b, const float* rstd_b,
+                        const float* gamma_b, int train_b, float* dgamma_b, float* dbeta_b, void* workspace, int io,
+                        void* stream);
+/* fp32 <-> bf16 copies of n elements (n % 4 == 0): the stem's fused BN+ReLU+pool kernels stay fp32; its pooled output
+ * and the gradient that comes back to it cross the bf16 boundary through these. */
+int hp_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+int hp_cast_bf16_to_f32(const void* x, float* y, long n, void* stream);
 /* MaxPool3d(kernel 3, stride 2, padding 1) (posenet3d_50.py:184), channels-last. */
 int hp_maxpool3d_k3s2_forward(const float* x, float* y, int B, int D, int H, int W, int C, void* stream);
 int hp_maxpool3d_k3s2_backward(const float* x, const float* y, const float* dy, float* dx, int B, int D, int H, int W,

@@ -346,3 +346,99 @@ def test_weight_gradients_on_side_stream_match_serial():
     got = grads(True)
     for k in ref:
         assert rel_l2(got[k], ref[k]) < 1e-4, k
+
+
+BF16S_CASES = [c for c in CASES if c[0] != "stem"]
+
+
+@pytest.mark.parametrize("name,cin,cout,k,s,p,tr,dims", BF16S_CASES, ids=[c[0] for c in BF16S_CASES])
+def test_conv_bf16_storage(name, cin, cout, k, s, p, tr, dims):
+    """BASELINE configs[2] storage: the same kernels with bf16 ACTIVATION tensors in memory (hp_conv_desc.io) -- the
+    gathered tensor read as 8-element bf16 runs (64-deep K tiles when the channel count allows, bf16 packed weights),
+    the written tensor optionally bf16.  Operands on the bf16 grid make the arithmetic exact up to accumulation order, so
+    the float64 operator is the expected value: fp32 outputs to the fp32 bar, bf16 outputs to one bf16 rounding."""
+    import ctypes as C
+
+    from hiddenpose_amd import _lib
+
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + 1)
+    B, D, H, W = dims
+    x = _bf16_grid(torch.randn(B, cin, D, H, W, generator=g))
+    w = _bf16_grid(torch.randn((cin, cout, k, k, k) if tr else (cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3 / s ** 3))
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv_transpose3d(xd, wd, stride=s, padding=p) if tr else F.conv3d(xd, wd, stride=s, padding=p)
+    gy = _bf16_grid(torch.randn(ref.shape, generator=g))
+    (ref * gy.double()).sum().backward()
+
+    L = _lib.lib()
+    xh = cl(x).cuda().bfloat16()
+    wc = w.cuda()
+    prev = ops.set_conv_precision("bf16s")
+    try:
+        desc = ops._desc(xh, cout, k, s, p, tr)
+    finally:
+        ops.set_conv_precision(prev)
+    assert desc.precision == 1
+    st = ops._stream(xh)
+    wh = ops._w_half(desc, True, cin)
+    assert wh == (cin % 64 == 0)
+    wf, _ = ops._pack(desc, wc, True, False, wh)
+    assert wf.dtype == (torch.bfloat16 if wh else torch.float32)
+    do, ho, wo = ops._out_dims(desc)
+    stats = torch.empty(2 * cout, dtype=torch.float64, device="cuda")
+    for yh in (False, True):
+        y = torch.empty(B, do, ho, wo, cout, device="cuda", dtype=torch.bfloat16 if yh else torch.float32)
+        desc.io = ops.HP_IO_X | (ops.HP_IO_W if wh else 0) | (ops.HP_IO_Y if yh else 0)
+        _lib.check(L.hp_conv3d_forward(C.byref(desc), xh.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st), "fwd")
+        assert rel_l2(ncdhw(y.float()), ref) < (4e-3 if yh else 2e-6)
+        refcl = cl(ref.detach())
+        assert rel_l2(stats[:cout], refcl.reshape(-1, cout).sum(0)) < 2e-5      # statistics come from the fp32 accumulators
+    dzh = cl(gy).cuda().bfloat16()
+    dx, dw = ops._conv_grads(desc, xh, wc, dzh, True)
+    assert dx.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    assert rel_l2(ncdhw(dx.float()), xd.grad) < 4e-3
+    assert rel_l2(dw, wd.grad) < 5e-6
+    # an addend of the data gradient (second contribution to the same tensor) in bf16 as well
+    add = _bf16_grid(torch.randn(xd.shape, generator=g))
+    if not (k == 1 and s == 2):   # the strided 1^3 data gradient accumulates in place (covered by the model tests)
+        dx2, _ = ops._conv_grads(desc, xh, wc, dzh, True, cl(add).cuda().bfloat16())
+        assert rel_l2(ncdhw(dx2.float()), xd.grad + add.double()) < 4e-3
+
+
+@pytest.mark.parametrize("with_res", [True, False])
+def test_conv_bn_act_unit_bf16_storage(with_res):
+    """One conv + BatchNorm + ReLU (+ residual) unit with bf16 activation storage against the same unit in the bf16
+    mode with fp32 storage (identical arithmetic; only the roundings of z, y, dz, dx differ: one bf16 ulp each)."""
+    g = torch.Generator().manual_seed(12)
+    B, C1, C2, D = 2, 64, 128, 6
+    conv = torch.nn.Conv3d(C1, C2, 3, padding=1, bias=False).cuda()
+    bn = torch.nn.BatchNorm3d(C2).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(_bf16_grid(torch.randn(conv.weight.shape, generator=g) * 0.05))
+        bn.weight.copy_(1 + 0.2 * torch.randn(C2, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C2, generator=g))
+    x = _bf16_grid(torch.randn(B, D, D, D, C1, generator=g)).cuda()
+    res = _bf16_grid(torch.randn(B, D, D, D, C2, generator=g)).cuda() if with_res else None
+    gy = _bf16_grid(torch.randn(B, D, D, D, C2, generator=g)).cuda()
+    out = {}
+    for mode in ("bf16", "bf16s"):
+        conv.zero_grad()
+        bn.zero_grad()
+        bn.train()
+        dt = torch.bfloat16 if mode == "bf16s" else torch.float32
+        xi = x.to(dt).requires_grad_(True)
+        ri = res.to(dt).requires_grad_(True) if with_res else None
+        prev = ops.set_conv_precision(mode)
+        try:
+            y = ops.conv_bn_act(xi, conv, bn, relu=True, residual=ri)
+        finally:
+            ops.set_conv_precision(prev)
+        assert y.dtype == dt
+        (y.float() * gy).sum().backward()
+        out[mode] = (y.detach().float(), xi.grad.float(), ri.grad.float() if with_res else None, conv.weight.grad.clone(),
+                     bn.weight.grad.clone(), bn.bias.grad.clone())
+    a, b = out["bf16"], out["bf16s"]
+    assert rel_l2(b[0], a[0]) < 6e-3 and rel_l2(b[1], a[1]) < 1.5e-2
+    if with_res:
+        assert rel_l2(b[2], a[2]) < 6e-3
+    assert rel_l2(b[3], a[3]) < 1.5e-2 and rel_l2(b[4], a[4]) < 1.5e-2 and rel_l2(b[5], a[5]) < 1.5e-2

@@ -90,6 +90,8 @@ def test_reducer_on_rccl_with_hip_gradients(rccl_world1, plain, algo, wire, side
         ref = g0[k]
         if ref.abs().max() == 0:
             assert p.grad.abs().max() == 0, k
+        elif k == "pose_net.head.features.9.bias":
+            continue   # the soft-max is shift invariant per joint: exact gradient 0, rounding noise in both runs
         elif k.startswith("autoencoder.") and k.endswith((".double_conv.0.bias", ".double_conv.3.bias")) and p.numel() == 4:
             # a convolution bias in front of a ONE-channel-per-group GroupNorm has no effect: its gradient is rounding
             # noise of either sign in both runs -- bounded, not compared

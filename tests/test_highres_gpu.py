@@ -145,22 +145,28 @@ def test_slab_fe_unet_vs_oracle():
     assert rel_l2(xg.grad, xr.grad.numpy()) < 2e-3
     for k, p in fe.named_parameters():
         assert rel_l2(p.grad, sdg["feature_extraction." + k].grad.numpy()) < 2e-3, k
-    # UNet3d on a [0, 10] input like normalize_feature's output
+    # UNet3d on a [0, 10] input like normalize_feature's output, against the oracle evaluated in FLOAT64 (the fp32
+    # oracle is shown beside it: ReLU / max-pool decisions that differ between two fp32 evaluations move gradients by
+    # percents, so fp32-vs-fp32 says little; the bar for ours is 2 x what the fp32 oracle itself shows, at least 2e-3)
     u = hpt.synthetic_meas(1, 64, 256, "uniform", seed=83) * 10.0
     keys = [k for k in sd if k.startswith("autoencoder.")]
-    sdg = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
-    ur = u.clone().requires_grad_(True)
-    rr = O.unet3d(ur, sdg)
-    (rr * gy).sum().backward()
+
+    def oracle_run(dt):
+        sdg = {k: (v.to(dt).clone().requires_grad_(True) if k in keys else v) for k, v in sd.items()}
+        ur = u.to(dt).clone().requires_grad_(True)
+        rr = O.unet3d(ur, sdg)
+        (rr * gy.to(dt)).sum().backward()
+        return rr.detach(), ur.grad, {k[len("autoencoder."):]: sdg[k].grad for k in keys}
+
+    r64, gu64, gp64 = oracle_run(torch.float64)
+    r32, gu32, gp32 = oracle_run(torch.float32)
     ug = u.cuda().requires_grad_(True)
     rg = un(ug)
     (rg * gy.cuda()).sum().backward()
-    assert rel_l2(rg, rr.detach().numpy()) < 1e-4
-    # backward: the forward agrees to ~1e-5, so about that fraction of the 4e6 x C ReLU decisions differs between the
-    # two fp32 evaluations and each flip is an O(1) change of one gradient element: rel-L2 ~ sqrt(1e-5) = 3e-3
-    assert rel_l2(ug.grad, ur.grad.numpy()) < 2e-2
+    assert rel_l2(rg, r64.numpy()) < 1e-4
+    assert rel_l2(ug.grad, gu64.numpy()) < max(2e-3, 2 * rel_l2(gu32, gu64.numpy()))
     for k, p in un.named_parameters():
-        ref = sdg["autoencoder." + k].grad
-        if k.endswith((".double_conv.0.bias", ".double_conv.3.bias")):
-            continue   # bias in front of GroupNorm: exact gradient ~0, rounding noise on both sides
-        assert rel_l2(p.grad, ref.numpy()) < 2e-2, k
+        if k.endswith((".double_conv.0.bias", ".double_conv.3.bias")) and p.numel() == 4:
+            continue   # bias in front of a one-channel-per-group GroupNorm: exact gradient 0
+        e, e32 = rel_l2(p.grad, gp64[k].numpy()), rel_l2(gp32[k], gp64[k].numpy())
+        assert e < max(2e-3, 2 * e32), (k, e, e32)
