@@ -183,6 +183,29 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
                                               double* __restrict__ stats, const void* __restrict__ addend,
                                               const unsigned char* __restrict__ amask, IgemmGeom g) {
   const float* const X = (const float*)Xv;  // fp32 view (stem: always fp32; otherwise only used when g.xh == 0)
+  // Runtime element types only in the single-plane bf16 kernels (NP = 1): the exact-fp32 and split kernels keep plain
+  // fp32 accesses (the uniform branch per access cost the fp32 headline step 3 %).
+  constexpr bool IOH = NP == 1;
+  auto ld_x4 = [&](long off) -> float4 {
+    if constexpr (IOH) return hp_ld4(Xv, off, g.xh);
+    else return *(const float4*)(X + off);
+  };
+  auto ld_a4 = [&](long off) -> float4 {
+    if constexpr (IOH) return hp_ld4(addend, off, g.ah);
+    else return *(const float4*)((const float*)addend + off);
+  };
+  auto ld_a1 = [&](long off) -> float {
+    if constexpr (IOH) return hp_ld1(addend, off, g.ah);
+    else return ((const float*)addend)[off];
+  };
+  auto st_y4 = [&](long off, float4 v) {
+    if constexpr (IOH) hp_st4(Y, off, v, g.yh);
+    else *(float4*)((float*)Y + off) = v;
+  };
+  auto st_y1 = [&](long off, float v) {
+    if constexpr (IOH) hp_st1(Y, off, v, g.yh);
+    else ((float*)Y)[off] = v;
+  };
   using C = TileCfg<BN>;
   // one LDS arena: A and B tiles during the K loop, then the output staging tile of the epilogue
   constexpr bool BF = NP > 0;  // NP = 0: exact-fp32 MFMA; NP >= 1: bf16 MFMA on NP operand planes
@@ -328,7 +351,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          ra[i] = (cok && (vmask[i] & 1ull)) ? hp_ld4(Xv, xb + rowoff[i], g.xh) : make_float4(0, 0, 0, 0);
+          ra[i] = (cok && (vmask[i] & 1ull)) ? ld_x4(xb + rowoff[i]) : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i)
           rbw[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i]) : make_float4(0, 0, 0, 0);
@@ -505,7 +528,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           }
           if (addend) {
-            float4 av = hp_ld4(addend, yo, g.ah);
+            float4 av = ld_a4(yo);
             if (amask) {  // byte per channel quad (hp_bn_apply's relu_mask): the addend is dy (.) mask, never stored
               const unsigned mk = amask[(orow * g.Nout + n) >> 2];
               av.x = (mk & 1u) ? av.x : 0.f;
@@ -515,12 +538,11 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
             }
             v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
           }
-          hp_st4(Y, yo, v, g.yh);
+          st_y4(yo, v);
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int e = 0; e < 4; ++e)
-            if (n + e < g.Nout)
-              hp_st1(Y, yo + e, vv[e] + (bias ? bias[n + e] : 0.f) + (addend ? hp_ld1(addend, yo + e, g.ah) : 0.f), g.yh);
+            if (n + e < g.Nout) st_y1(yo + e, vv[e] + (bias ? bias[n + e] : 0.f) + (addend ? ld_a1(yo + e) : 0.f));
         }
       }
     }
@@ -542,8 +564,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         for (int j = 0; j < C::TN; ++j) {
           const int n = n0 + wn * C::TN * 32 + j * 32 + (lane & 31);
           if (n < g.Nout)
-            hp_st1(Y, orow * g.Nout + n,
-                   acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? hp_ld1(addend, orow * g.Nout + n, g.ah) : 0.f), g.yh);
+            st_y1(orow * g.Nout + n, acc[i][j][r] + (bias ? bias[n] : 0.f) + (addend ? ld_a1(orow * g.Nout + n) : 0.f));
         }
       }
     }
@@ -603,19 +624,34 @@ template <bool STEM, int TT, int NTAP, int NP, bool XH = false>
 __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const void* __restrict__ dY,
                                               float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit,
                                               int tiles_total, int tap_groups) {
-  const float* const X = (const float*)Xv;  // stem: always fp32.  g.xh / g.yh: element type of X / dY
+  const float* const X = (const float*)Xv;  // stem: always fp32.  g.xh / g.yh: element type of X / dY (NP = 1 only)
+  constexpr bool IOH = NP == 1;
+  auto ld_y4 = [&](long off) -> float4 {
+    if constexpr (IOH) return hp_ld4(dY, off, g.yh);
+    else return *(const float4*)((const float*)dY + off);
+  };
+  auto ld_y1 = [&](long off) -> float {
+    if constexpr (IOH) return hp_ld1(dY, off, g.yh);
+    else return ((const float*)dY)[off];
+  };
+  auto ld_x4 = [&](long off) -> float4 {
+    if constexpr (IOH) return hp_ld4(Xv, off, g.xh);
+    else return *(const float4*)(X + off);
+  };
   static_assert(!XH || (NP == 1 && !STEM), "bf16-storage staging: single bf16 plane, not the stem");
+  // voxels per step (128 / 64 per step for the bf16-storage variant were measured: 6 % slower than 32)
+  constexpr int KM = WG_KM;
   constexpr int EPL = XH ? 8 : 4;       // elements per thread, row and load
   constexpr int QN = TT / EPL;          // 16-byte loads per staged row
   constexpr int RPP = CT / QN;          // rows per staging pass
-  constexpr int RPT = WG_KM / RPP;      // rows per thread
+  constexpr int RPT = KM / RPP;      // rows per thread
   static_assert(RPT >= 1, "staging pass covers at most one step");
   constexpr int WT = TT / 64;           // 32x32 tiles per wave per dim
   static_assert(NTAP == 1 || TT == 64, "multi-tap blocks use the 64x64 tile");
   constexpr bool BF = NP > 0;
   constexpr int NPL = NP > 0 ? NP : 1;
   constexpr int LDT = TT + 32;
-  constexpr int YSZ = WG_KM * TT > NP * WG_KM * LDT / 2 ? WG_KM * TT : NP * WG_KM * LDT / 2;  // floats
+  constexpr int YSZ = XH ? KM * LDT / 2 : (KM * TT > NP * KM * LDT / 2 ? KM * TT : NP * KM * LDT / 2);  // floats
   __shared__ __attribute__((aligned(16))) float Ys[YSZ];
   __shared__ __attribute__((aligned(16))) float Xs[NTAP * YSZ];
   // BF: the tiles are kept as bf16 [voxel][TT + 32]; the matrix cores want 8 consecutive voxels (the GEMM K
@@ -655,7 +691,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
     tv[t] = tap + t < ntaps_cls;
     if (!STEM && tv[t]) tap_info(g, cls, tap + t, dz[t], dy[t], dx[t], widx[t]);
   }
-  const long chunk = ((g.M + msplit - 1) / msplit + WG_KM - 1) / WG_KM * WG_KM;
+  const long chunk = ((g.M + msplit - 1) / msplit + KM - 1) / KM * KM;
   const long mbeg = (long)bid_split * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
   const int Kc = STEM ? g.kpt * BK : g.Cin;  // extent of the c axis
   const int sq = tid % QN, sr = tid / QN;
@@ -713,11 +749,11 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
         const long orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
         const int n = n0 + sq * 4;
         if (n + 3 < g.Nout) {
-          vy[h] = hp_ld4(dY, orow * g.Nout + n, g.yh);
+          vy[h] = ld_y4(orow * g.Nout + n);
         } else if (n < g.Nout) {
           float t4[4] = {0, 0, 0, 0};
           for (int e = 0; e < 4; ++e)
-            if (n + e < g.Nout) t4[e] = hp_ld1(dY, orow * g.Nout + n + e, g.yh);
+            if (n + e < g.Nout) t4[e] = ld_y1(orow * g.Nout + n + e);
           vy[h] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
         if constexpr (STEM) {
@@ -739,7 +775,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
             const int zz = z * g.s + dz[t], yy = y * g.s + dy[t], xx = x * g.s + dx[t];
             if (tv[t] && (unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi &&
                 c < g.Cin)
-              vx[t][h] = hp_ld4(Xv, (long)(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c, g.xh);
+              vx[t][h] = ld_x4((long)(unsigned)(((b * g.Di + zz) * g.Hi + yy) * g.Wi + xx) * g.Cin + c);
           }
         }
       }
@@ -747,34 +783,34 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
   };
 
   if (mbeg < mend) load_step(mbeg);
-  for (long mb = mbeg; mb < mend; mb += WG_KM) {
+  for (long mb = mbeg; mb < mend; mb += KM) {
     __syncthreads();  // fragment reads of the previous step are done
 #pragma unroll
     for (int h = 0; h < RPT; ++h) {
       if constexpr (XH) {
         *(uint4*)(Yh + (sr + RPP * h) * LDT + sq * 8) = hy[h];
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) *(uint4*)(Xh + (t * WG_KM + sr + RPP * h) * LDT + sq * 8) = hx[t][h];
+        for (int t = 0; t < NTAP; ++t) *(uint4*)(Xh + (t * KM + sr + RPP * h) * LDT + sq * 8) = hx[t][h];
       } else if constexpr (BF) {
         bf16x4 pl[NPL];
         split_bf16<NPL>(vy[h], pl);
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) *(bf16x4*)(Yh + (p * WG_KM + sr + RPP * h) * LDT + sq * 4) = pl[p];
+        for (int p = 0; p < NPL; ++p) *(bf16x4*)(Yh + (p * KM + sr + RPP * h) * LDT + sq * 4) = pl[p];
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
           split_bf16<NPL>(vx[t][h], pl);
 #pragma unroll
           for (int p = 0; p < NPL; ++p)
-            *(bf16x4*)(Xh + ((t * NPL + p) * WG_KM + sr + RPP * h) * LDT + sq * 4) = pl[p];
+            *(bf16x4*)(Xh + ((t * NPL + p) * KM + sr + RPP * h) * LDT + sq * 4) = pl[p];
         }
       } else {
         *(float4*)(Ys + (sr + RPP * h) * TT + sq * 4) = vy[h];
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) *(float4*)(Xs + (t * WG_KM + sr + RPP * h) * TT + sq * 4) = vx[t][h];
+        for (int t = 0; t < NTAP; ++t) *(float4*)(Xs + (t * KM + sr + RPP * h) * TT + sq * 4) = vx[t][h];
       }
     }
     __syncthreads();
-    if (mb + WG_KM < mend) load_step(mb + WG_KM);
+    if (mb + KM < mend) load_step(mb + KM);
     if constexpr (BF) {
       // 16-lane group gq of the wave: voxels 8*(gq>>1) .. +7 of the K step, channels 16*(gq&1) .. +15 of the
       // 32-wide tile; lane 4q+p of the group addresses row q, columns 4p .. 4p+3 (two reads: rows +0, +4)
@@ -792,13 +828,13 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
       };
       using ST = SplitTerms<NPL>;
 #pragma unroll
-      for (int ks = 0; ks < WG_KM / 16; ++ks) {
+      for (int ks = 0; ks < KM / 16; ++ks) {
         bf16x8 ha[NPL][WT];
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
           for (int i = 0; i < WT; ++i)
-            ha[p][i] = tr8(Yh + (p * WG_KM + ks * 16 + trow) * LDT + wn * (TT / 2) + i * 32 + tcol);
+            ha[p][i] = tr8(Yh + (p * KM + ks * 16 + trow) * LDT + wn * (TT / 2) + i * 32 + tcol);
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
           bf16x8 hb[NPL][WT];
@@ -806,7 +842,7 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
           for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int j = 0; j < WT; ++j)
-              hb[p][j] = tr8(Xh + ((t * NPL + p) * WG_KM + ks * 16 + trow) * LDT + wc * (TT / 2) + j * 32 + tcol);
+              hb[p][j] = tr8(Xh + ((t * NPL + p) * KM + ks * 16 + trow) * LDT + wc * (TT / 2) + j * 32 + tcol);
 #pragma unroll
           for (int u = 0; u < ST::N; ++u)
 #pragma unroll
@@ -827,13 +863,13 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
 #pragma unroll
       for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) fb[set][t][j] = Xs[(t * WG_KM + mrow) * TT + wc * (TT / 2) + j * 32 + (lane & 31)];
+        for (int j = 0; j < WT; ++j) fb[set][t][j] = Xs[(t * KM + mrow) * TT + wc * (TT / 2) + j * 32 + (lane & 31)];
     };
     frag(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < WG_KM / 2; ++kk) {
+    for (int kk = 0; kk < KM / 2; ++kk) {
       const int cur = kk & 1;
-      if (kk + 1 < WG_KM / 2) frag(cur ^ 1, kk + 1);
+      if (kk + 1 < KM / 2) frag(cur ^ 1, kk + 1);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
       for (int t = 0; t < NTAP; ++t)
@@ -1484,6 +1520,7 @@ static void set_shifts(IgemmGeom& g) {
 static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
   HP_REQUIRE(d.B >= 1 && d.Cin >= 1 && d.Cout >= 1, "conv: bad channel/batch sizes");
   HP_REQUIRE(d.precision >= HP_PRECISION_FP32 && d.precision <= HP_PRECISION_BF16X6, "conv: unknown precision %d", d.precision);
+  HP_REQUIRE(d.io == 0 || d.precision == HP_PRECISION_BF16, "conv: bf16 activation tensors (io = %d) go with HP_PRECISION_BF16", d.io);
   p.planes = d.precision;  // HP_PRECISION_* = number of bf16 operand planes (0: exact-fp32 MFMA)
   const int k = d.k, s = d.stride, pad = d.pad;
   IgemmGeom f{};

@@ -19,7 +19,11 @@ def test_visible_net_vs_reference_golden(golden):
     assert y.shape == g["y"].shape
     c = g["x"].shape[1]
     assert rel_l2(y[:, :c], g["y"][:, :c]) < 1e-6            # the four largest values, descending
-    assert np.array_equal(y[:, c:].cpu().numpy(), g["y"][:, c:])   # their depth coordinates, exactly
+    # their depth coordinates, exactly -- wherever the value is positive (zeros left by the ReLU tie, and torch.topk's
+    # order among equal values is unspecified)
+    pos = g["y"][:, :c] > 0
+    assert pos.mean() > 0.9
+    assert np.array_equal(y[:, c:].cpu().numpy()[pos], g["y"][:, c:][pos])
 
 
 def test_weighted_mse_forward_backward():

