@@ -96,6 +96,7 @@ SIGNATURES = {
     "hp_sformer_patchify": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "hp_layernorm_forward": (_i, [_fp, _fp, C.c_long, _i, _fp, _fp, C.c_float, _i, C.c_long, _vp]),
     "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),
+    "hp_gelu_forward": (_i, [_fp, _fp, C.c_long, _vp]),
     "hp_sformer_qkv_prepare": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, C.c_float, _fp, _fp, _i, _vp]),
     "hp_sformer_attention_workspace_bytes": (_sz, [_i, _i, _i]),
     "hp_lct_time_window": (_i, [_fp, _fp, _i, _i, _i, _i, C.c_long, C.POINTER(C.c_int), _i, _vp]),

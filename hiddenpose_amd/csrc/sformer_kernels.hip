@@ -78,6 +78,14 @@ __global__ __launch_bounds__(ST) void k_geglu(const float* __restrict__ u, float
   }
 }
 
+// plain GELU (erf form: nn.GELU() of models/tokenpose.py:274), rows x dim elementwise
+__global__ __launch_bounds__(ST) void k_gelu(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * ST + threadIdx.x; i < n; i += (long)gridDim.x * ST) {
+    const float v = x[i];
+    y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  }
+}
+
 // qkv (B, Ntok, 3*inner) -> Q, K, V (B, heads, Ntok, dh); q scaled; axial RoPE on the patch tokens'
 // q and k: t' = t * cos + rotate_every_two(t) * sin on the first rot_dim dims (tables (n, rot_dim)).
 __global__ __launch_bounds__(ST) void k_qkv_prepare(const float* __restrict__ qkv, float* __restrict__ Q,
@@ -453,6 +461,15 @@ extern "C" int hp_geglu_forward(const float* u, float* g, long rows, int hidden,
   return HP_OK;
 }
 
+extern "C" int hp_gelu_forward(const float* x, float* y, long n, void* stream) {
+  HP_REQUIRE(x && y && n > 0, "hp_gelu_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("gelu", st);
+  hipLaunchKernelGGL(k_gelu, dim3(sgrid(n)), dim3(ST), 0, st, x, y, n);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
 extern "C" int hp_sformer_qkv_prepare(const float* qkv, float* Q, float* K, float* K0, float* V, int B, int Ntok, int heads,
                                       int dh,
                                       int num_joints, int patches_per_frame, float scale, const float* sin_t,
@@ -480,8 +497,8 @@ extern "C" int hp_sformer_attention(const float* Q, const float* K, const float*
   HP_REQUIRE(num_joints <= 32 && Ntok == num_joints + frames * patches_per_frame, "hp_sformer_attention: bad token layout");
   HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_sformer_attention: precision %d not built",
              precision);
-  if (dh != 16 && dh != 32) {
-    set_error("hp_sformer_attention: dim_head %d not built (16, 32)", dh);
+  if (dh != 16 && dh != 24 && dh != 32) {
+    set_error("hp_sformer_attention: dim_head %d not built (16, 24, 32)", dh);
     return HP_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -495,11 +512,13 @@ extern "C" int hp_sformer_attention(const float* Q, const float* K, const float*
       hipLaunchKernelGGL(k_attention_patch_bf16, gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame,
                          frames);
     else if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
+    else if (dh == 24) hipLaunchKernelGGL((k_attention<24>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
     else hipLaunchKernelGGL((k_attention<16>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
   }
-  {
+  if (num_joints > 0) {  // (TokenPose's all-to-all attention has no separate joint / class queries)
     HP_PROF("sformer_attention_joint", st);
     if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1, part);
+    else if (dh == 24) hipLaunchKernelGGL((k_attention<24>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1, part);
     else hipLaunchKernelGGL((k_attention<16>), gj, dim3(ST), 0, st, Q, K0, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 1, part);
     const int total = B * heads * num_joints * dh;
     hipLaunchKernelGGL(k_attention_joint_merge, dim3((total + 255) / 256), dim3(256), 0, st, part, out, B * heads, heads, dh, Ntok,

@@ -344,6 +344,8 @@ int hp_sformer_patchify(const float* video, float* tokens, int B, int frames, in
  * (r / rows_per_batch) * batch_stride_rows + r % rows_per_batch of x (the joint tokens of every batch). */
 int hp_layernorm_forward(const float* x, float* y, long rows, int dim, const float* gamma, const float* beta, float eps,
                          int rows_per_batch, long batch_stride_rows, void* stream);
+/* nn.GELU() (erf form; models/tokenpose.py:271-277 FeedForward), elementwise over n values */
+int hp_gelu_forward(const float* x, float* y, long n, void* stream);
 /* GEGLU (:197-201): g = u[:, :hidden] * gelu(u[:, hidden:]) with the exact (erf) GELU */
 int hp_geglu_forward(const float* u, float* g, long rows, int hidden, void* stream);
 /* chunk(3) + 'b n (h d) -> (b h) n d' + q * scale + axial RoPE on the patch tokens (:160-172, :298-313).

@@ -547,6 +547,60 @@ def sec_sformer():
     save("sformer_io.npz", **out)
 
 
+TIMESFORMER_CFGS = {
+    "plain": dict(dim=64, num_frames=4, num_classes=10, image_size=32, patch_size=8, channels=1, depth=2, heads=4, dim_head=16),
+    "shift": dict(dim=96, num_frames=3, num_classes=10, image_size=32, patch_size=4, channels=2, depth=2, heads=2, dim_head=32,
+                  shift_tokens=True),
+}
+TOKENPOSE_CFGS = {
+    "sinefull": dict(feature_size=[16, 16], patch_size=[4, 4], num_keypoints=6, dim=48, depth=2, heads=2, mlp_dim=96,
+                     heatmap_dim=64, heatmap_size=[8, 8], channels=4, pos_embedding_type="sine-full", hidden_heatmap_dim=64),
+    "learnable": dict(feature_size=[16, 24], patch_size=[4, 4], num_keypoints=5, dim=64, depth=1, heads=4, mlp_dim=128,
+                      heatmap_dim=48, heatmap_size=[8, 6], channels=3, pos_embedding_type="learnable", hidden_heatmap_dim=64),
+}
+
+
+def sec_xformers():
+    """The orphan transformer heads of SURVEY 8(f) rank 1: TimeSformer (models/transformer.py:152-257, with and without
+    token shift) and TokenPose_L_base (models/tokenpose.py:66-227)."""
+    import contextlib
+    import io
+    import json
+
+    from models.tokenpose import TokenPose_L_base
+    from models.transformer import TimeSformer
+
+    out, schema = {}, {}
+    for tag, kw in TIMESFORMER_CFGS.items():
+        m = TimeSformer(**kw)
+        hpt.fill_module(m, "timesformer.")
+        with torch.no_grad():
+            m.cls_token.copy_(hpt.fill_value("timesformer.cls_token", m.cls_token.shape))
+        m.eval()
+        g = torch.Generator().manual_seed(78)
+        video = torch.rand(2, kw["num_frames"], kw["channels"], kw["image_size"], kw["image_size"], generator=g)
+        with torch.no_grad():
+            y = m(video)
+        out["ts_" + tag + "_y"] = y.numpy()
+        schema["ts_" + tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        print(f"  TimeSformer {tag}: out {tuple(y.shape)} std {y.std().item():.3g}")
+    for tag, kw in TOKENPOSE_CFGS.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = TokenPose_L_base(**kw)
+        hpt.fill_module(m, "tokenpose.")
+        m.eval()
+        g = torch.Generator().manual_seed(79)
+        feat = torch.rand(2, kw["channels"], kw["feature_size"][0], kw["feature_size"][1], generator=g)
+        with torch.no_grad():
+            y = m(feat)
+        out["tp_" + tag + "_y"] = y.numpy()
+        schema["tp_" + tag] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        print(f"  TokenPose {tag}: out {tuple(y.shape)} std {y.std().item():.3g}")
+    save("xformers_io.npz", **out)
+    with open(os.path.join(HERE, "xformers_schema.json"), "w") as f:
+        json.dump(schema, f, indent=0)
+
+
 def sec_schema():
     """state_dict key names and shapes of the reference NlosPose (checkpoint contract)."""
     import json
@@ -636,7 +690,7 @@ def sec_ingest():
 
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
-            "specular": sec_specular, "visible": sec_visible, "e2e128train": sec_e2e128train, "highres": sec_highres}
+            "specular": sec_specular, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "highres": sec_highres}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

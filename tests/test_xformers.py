@@ -1,0 +1,102 @@
+"""TimeSformer (models/transformer.py) and TokenPose-L (models/tokenpose.py), SURVEY 8(f) rank 1: the oracle against
+goldens captured from the reference (CPU), the state_dict schemas, and the HIP modules against the same goldens (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hiddenpose_amd import testing as hpt
+from oracle import nlospose_oracle as O
+from util import rel_l2
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TS = {
+    "plain": dict(dim=64, num_frames=4, num_classes=10, image_size=32, patch_size=8, channels=1, depth=2, heads=4, dim_head=16),
+    "shift": dict(dim=96, num_frames=3, num_classes=10, image_size=32, patch_size=4, channels=2, depth=2, heads=2, dim_head=32,
+                  shift_tokens=True),
+}
+TP = {
+    "sinefull": dict(feature_size=[16, 16], patch_size=[4, 4], num_keypoints=6, dim=48, depth=2, heads=2, mlp_dim=96,
+                     heatmap_dim=64, heatmap_size=[8, 8], channels=4, pos_embedding_type="sine-full", hidden_heatmap_dim=64),
+    "learnable": dict(feature_size=[16, 24], patch_size=[4, 4], num_keypoints=5, dim=64, depth=1, heads=4, mlp_dim=128,
+                      heatmap_dim=48, heatmap_size=[8, 6], channels=3, pos_embedding_type="learnable", hidden_heatmap_dim=64),
+}
+
+
+def _ts(tag):
+    from hiddenpose_amd.transformer import TimeSformer
+
+    m = TimeSformer(**TS[tag])
+    hpt.fill_module(m, "timesformer.")
+    with torch.no_grad():
+        m.cls_token.copy_(hpt.fill_value("timesformer.cls_token", m.cls_token.shape))
+    g = torch.Generator().manual_seed(78)
+    kw = TS[tag]
+    return m, torch.rand(2, kw["num_frames"], kw["channels"], kw["image_size"], kw["image_size"], generator=g)
+
+
+def _tp(tag):
+    from hiddenpose_amd.tokenpose import TokenPose_L_base
+
+    m = TokenPose_L_base(**TP[tag])
+    hpt.fill_module(m, "tokenpose.")
+    g = torch.Generator().manual_seed(79)
+    kw = TP[tag]
+    return m, torch.rand(2, kw["channels"], kw["feature_size"][0], kw["feature_size"][1], generator=g)
+
+
+@pytest.mark.parametrize("tag", list(TS))
+def test_timesformer_schema_and_oracle(tag, golden):
+    m, video = _ts(tag)
+    schema = json.load(open(os.path.join(HERE, "golden", "xformers_schema.json")))["ts_" + tag]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == schema
+    y = O.timesformer(video, m.state_dict(), patch_size=TS[tag]["patch_size"], heads=TS[tag]["heads"],
+                      shift_tokens=TS[tag].get("shift_tokens", False))
+    assert rel_l2(y, golden("xformers_io.npz")["ts_" + tag + "_y"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag", list(TP))
+def test_tokenpose_schema_and_oracle(tag, golden):
+    m, feat = _tp(tag)
+    schema = json.load(open(os.path.join(HERE, "golden", "xformers_schema.json")))["tp_" + tag]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == schema
+    kw = TP[tag]
+    y = O.tokenpose_base(feat, m.state_dict(), patch_size=kw["patch_size"][0], heads=kw["heads"], num_keypoints=kw["num_keypoints"],
+                         heatmap_size=kw["heatmap_size"], pos_embedding_type=kw["pos_embedding_type"])
+    assert rel_l2(y, golden("xformers_io.npz")["tp_" + tag + "_y"]) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(TS))
+def test_timesformer_on_device_vs_reference_golden(tag, golden):
+    m, video = _ts(tag)
+    y = m.cuda().eval()(video.cuda())
+    assert y.shape == (2, 72)
+    assert rel_l2(y, golden("xformers_io.npz")["ts_" + tag + "_y"]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(TP))
+def test_tokenpose_on_device_vs_reference_golden(tag, golden):
+    m, feat = _tp(tag)
+    y = m.cuda().eval()(feat.cuda())
+    assert rel_l2(y, golden("xformers_io.npz")["tp_" + tag + "_y"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_tokenpose_l_config_geometry_vs_oracle():
+    """TokenPose-L as models/token_config.py configures it (dim 192, 8 heads of 24, 16 keypoints, 256 patches of 4 x 4 x
+    128 channels, depth 2 per stage, 64 x 64 heat-maps) against the oracle."""
+    from hiddenpose_amd.tokenpose import TokenPose_L_base
+
+    kw = dict(feature_size=[64, 64], patch_size=[4, 4], num_keypoints=16, dim=192, depth=2, heads=8, mlp_dim=576,
+              heatmap_dim=4096, heatmap_size=[64, 64], channels=128, pos_embedding_type="sine-full", hidden_heatmap_dim=384)
+    m = TokenPose_L_base(**kw)
+    hpt.fill_module(m, "tokenpose.")
+    g = torch.Generator().manual_seed(80)
+    feat = torch.rand(1, 128, 64, 64, generator=g)
+    ref = O.tokenpose_base(feat, m.state_dict(), patch_size=4, heads=8, num_keypoints=16, heatmap_size=[64, 64])
+    y = m.cuda().eval()(feat.cuda())
+    assert rel_l2(y, ref) < 1e-4
