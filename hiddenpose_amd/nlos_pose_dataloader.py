@@ -22,12 +22,18 @@ from . import _lib
 FRAMES, KEEP_FRAMES = 600, 512  # rearrange '(t h) w -> t h w', t=600 and [:512]  (:107)
 
 
-def decode_hdr(path: str) -> np.ndarray:
-    """Radiance file -> (rows, W, 4) uint8 RGBE on the host (file parsing only; hp_rgbe_decode)."""
+def decode_hdr(path: str, pinned=None):
+    """Radiance file -> (rows, W, 4) uint8 RGBE on the host (file parsing only; hp_rgbe_decode).  `pinned`: a callable
+    nbytes -> page-locked uint8 torch tensor to decode into (the result is then a view of it, a torch tensor)."""
     L = _lib.lib()
     raw = np.fromfile(path, dtype=np.uint8)
     w, h = C.c_int(0), C.c_int(0)
     _lib.check(L.hp_rgbe_decode(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), None, 0), "hp_rgbe_decode")
+    n = h.value * w.value * 4
+    if pinned is not None:
+        buf = pinned(n)
+        _lib.check(L.hp_rgbe_decode(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), buf.data_ptr(), n), "hp_rgbe_decode")
+        return buf[:n].view(h.value, w.value, 4)
     out = np.empty((h.value, w.value, 4), np.uint8)
     _lib.check(L.hp_rgbe_decode(raw.ctypes.data, raw.size, C.byref(w), C.byref(h), out.ctypes.data, out.nbytes), "hp_rgbe_decode")
     return out
@@ -102,6 +108,25 @@ class NlosPoseDataset(Dataset):
         for kind, files in (("meas", self.measFiles), ("vol", self.volFiles), ("joints", self.jointsFiles)):
             print(f"total {self.phase} {kind} is {len(files)}")
 
+    # ---- host half (file I/O + run-length expansion; runs in worker threads of PrefetchingLoader) ----------------
+    def load_host(self, index, pinned=None):
+        """Everything of sample `index` that needs no GPU: the expanded RGBE image (uint8, pinned if `pinned` hands a
+        reusable page-locked buffer), the raw volume, the remapped joints.  Raises on an unreadable measurement."""
+        from scipy.io import loadmat
+
+        meas_file, joint_file = self.measFiles[index], self.jointsFiles[index]
+        rgbe = decode_hdr(meas_file, pinned)
+        vol = loadmat(self.volFiles[index])["vol"].astype(np.float32)
+        joints = remap_joints(np.loadtxt(joint_file), self.vol_size[0], self.heatmap_size[0])
+        return {"rgbe": rgbe, "vol": vol, "joints": joints, "id": os.path.splitext(os.path.basename(meas_file))[0]}
+
+    # ---- device half (decode, normalisations, gray, crop, pyramids; on the CURRENT stream) ---------------------------
+    def to_device(self, host):
+        rgbe = host["rgbe"] if torch.is_tensor(host["rgbe"]) else torch.from_numpy(host["rgbe"])
+        meas = rgbe_to_meas(rgbe.to(self.device, non_blocking=True), self.downsample_cnt)
+        vol = box_pyramid(torch.from_numpy(host["vol"]).to(self.device, non_blocking=True), self.downsample_cnt)
+        return meas[None], vol[None]
+
     def _meas(self, path):
         rgbe = torch.from_numpy(decode_hdr(path)).to(self.device, non_blocking=True)
         return rgbe_to_meas(rgbe, self.downsample_cnt)
@@ -125,3 +150,147 @@ class NlosPoseDataset(Dataset):
 
     def __len__(self):
         return len(self.volFiles)
+
+
+class PrefetchingLoader:
+    """Batches of a NlosPoseDataset with the ingest overlapped with training (reference: DataLoader(num_workers=8,
+    pin_memory=True), train.py:119-122, whose workers decode on the CPU).
+
+    * `workers` host threads read the files and expand the Radiance run-length container (hp_rgbe_decode releases the
+      GIL) straight into recycled page-locked buffers;
+    * one device thread copies each expanded image to the GPU and runs the ingest kernels on a SIDE stream, stacks the
+      batch and records an event;
+    * the consumer's stream waits on that event only -- at 128^3 the 157 MB image of a sample otherwise serialises
+      file read + expansion + H2D with the training step (~26 samples/s).
+    `depth` batches are kept ready.  Sample order = `sampler` if given, else range(len) (shuffled with `seed` + epoch
+    when `shuffle`).  A measurement that cannot be read (or is all zero) is replaced by sample 0 as in the reference."""
+
+    def __init__(self, dataset, batch_size, sampler=None, shuffle=False, drop_last=True, depth=2, workers=4, seed=410):
+        self.ds, self.bs, self.sampler, self.shuffle, self.drop_last = dataset, int(batch_size), sampler, shuffle, drop_last
+        self.depth, self.workers, self.seed, self.epoch = max(1, depth), max(1, workers), seed, 0
+        self._free = []          # recycled pinned buffers
+        import threading
+
+        self._lock = threading.Lock()
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+        if self.sampler is not None and hasattr(self.sampler, "set_epoch"):
+            self.sampler.set_epoch(epoch)
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else len(self.ds)
+        return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
+
+    def _indices(self):
+        if self.sampler is not None:
+            return list(iter(self.sampler))
+        n = len(self.ds)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            return torch.randperm(n, generator=g).tolist()
+        return list(range(n))
+
+    def _pinned(self, nbytes):
+        with self._lock:
+            for i, t in enumerate(self._free):
+                if t.numel() >= nbytes:
+                    return self._free.pop(i)
+        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+
+    def _recycle(self, t):
+        base = t._base if t._base is not None else t
+        with self._lock:
+            if len(self._free) < self.depth * self.bs + self.workers:
+                self._free.append(base.reshape(-1))
+
+    def __iter__(self):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        ds, dev = self.ds, self.ds.device
+        idx = self._indices()
+        nb = len(self)
+        batches = [idx[i * self.bs:(i + 1) * self.bs] for i in range(nb)]
+        ready = queue.Queue(maxsize=self.depth)
+        pool = ThreadPoolExecutor(max_workers=self.workers)
+        stop = threading.Event()
+
+        def host(i):
+            try:
+                return ds.load_host(i, self._pinned)
+            except Exception:
+                print(f"--------------------\nNo.{i} {ds.measFiles[i]} meas is wrong. \n--------------------------\n")
+                ds.wrongMeasFiles.append(ds.measFiles[i])
+                h0 = ds.load_host(0, self._pinned)
+                try:   # the reference keeps the failing sample's volume
+                    from scipy.io import loadmat
+
+                    h0["vol"] = loadmat(ds.volFiles[i])["vol"].astype(np.float32)
+                except Exception:
+                    pass
+                return h0
+
+        def device_stage():
+            side = torch.cuda.Stream(dev)
+            try:
+                # host loads are submitted `depth` batches ahead of the device stage
+                futs = {}
+                nxt = 0
+                ahead = self.depth + 1
+                for bi, batch in enumerate(batches):
+                    while nxt < min(len(batches), bi + ahead):
+                        futs[nxt] = [pool.submit(host, i) for i in batches[nxt]]
+                        nxt += 1
+                    items = [f.result() for f in futs.pop(bi)]
+                    if stop.is_set():
+                        return
+                    with torch.cuda.device(dev), torch.cuda.stream(side):
+                        ms, vs = [], []
+                        for k, h in enumerate(items):
+                            try:
+                                m, v = ds.to_device(h)
+                            except ValueError:   # all-zero measurement (:75): sample 0 instead
+                                h0 = host(0)
+                                m, _ = ds.to_device(h0)
+                                _, v = ds.to_device({"rgbe": h0["rgbe"], "vol": h["vol"]})
+                                items[k] = dict(h0, vol=h["vol"])
+                            ms.append(m)
+                            vs.append(v)
+                        meas, vol = torch.stack(ms), torch.stack(vs)
+                        joints = torch.stack([torch.as_tensor(h["joints"], dtype=torch.float32) for h in items]).to(dev, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    ids = [h["id"] for h in items]
+                    side.synchronize()     # the pinned buffers may be reused once their copies are done
+                    for h in items:
+                        if torch.is_tensor(h["rgbe"]):
+                            self._recycle(h["rgbe"])
+                    ready.put((meas, vol, joints, ids, ev))
+                ready.put(None)
+            except BaseException as e:   # surface worker failures in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=device_stage, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                meas, vol, joints, ids, ev = item
+                torch.cuda.current_stream(dev).wait_event(ev)
+                for t in (meas, vol, joints):
+                    t.record_stream(torch.cuda.current_stream(dev))
+                yield meas, vol, joints, ids
+        finally:
+            stop.set()
+            while th.is_alive():   # drain so that the producer can finish
+                try:
+                    ready.get(timeout=0.1)
+                except queue.Empty:
+                    pass
+            pool.shutdown(wait=False)

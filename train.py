@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader
 
 from hiddenpose_amd.cli import build_config, load_checkpoint, parse_args
 from hiddenpose_amd.NlosPose import NlosPose
-from hiddenpose_amd.nlos_pose_dataloader import NlosPoseDataset
+from hiddenpose_amd.nlos_pose_dataloader import NlosPoseDataset, PrefetchingLoader
 from hiddenpose_amd.train_epoch import build_training, checkpoint_dict, save_checkpoint, seed_everything, train_epoch
 
 
@@ -65,9 +65,14 @@ def main(argv=None):
         from torch.utils.data.distributed import DistributedSampler
 
         sampler = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, seed=410)
-    # the dataset decodes on the GPU: workers would each need a device context, so samples are produced in-process
-    loader = DataLoader(data, batch_size=cfg.TRAIN.BATCH_SIZE, shuffle=sampler is None, sampler=sampler, num_workers=0,
-                        collate_fn=_collate, drop_last=True)
+    # Host threads read + expand the .hdr files into pinned memory, a side stream copies and runs the ingest kernels:
+    # the training stream never waits for a file (HP_LOADER=simple: the in-process torch DataLoader instead)
+    if os.environ.get("HP_LOADER", "prefetch") == "simple":
+        loader = DataLoader(data, batch_size=cfg.TRAIN.BATCH_SIZE, shuffle=sampler is None, sampler=sampler, num_workers=0,
+                            collate_fn=_collate, drop_last=True)
+    else:
+        loader = PrefetchingLoader(data, cfg.TRAIN.BATCH_SIZE, sampler=sampler, shuffle=sampler is None, drop_last=True,
+                                   depth=2, workers=int(os.environ.get("HP_LOADER_WORKERS", "4")), seed=410)
 
     stamp = f"{time.gmtime().tm_mon}_{time.gmtime().tm_mday}_{cfg.LOSS.TYPE}_{cfg.MODEL.COORD_REPRESENTATION}"
     save_model_dir = os.path.join(cfg.RESULT.FINAL_OUTPUT_DIR, stamp)
@@ -89,12 +94,16 @@ def main(argv=None):
         t0 = time.time()
         if sampler is not None:
             sampler.set_epoch(epoch)
+        if hasattr(loader, "set_epoch"):
+            loader.set_epoch(epoch)
         lr_scheduler.step()  # the reference steps the schedule before the epoch's first optimizer step
         mean_loss = train_epoch(cfg, loader, model, criterion, voxel_criterion, optimizer, epoch, cfg.RESULT.FINAL_OUTPUT_DIR,
                                 writer, begin_time, save_model_dir, lr_scheduler, reducer=reducer, max_steps=args.max_steps)
         if rank == 0:
             dt = time.time() - t0
-            print(f"epoch {epoch} used {dt}, mean loss {mean_loss}, left {dt * (cfg.TRAIN.END_EPOCH - epoch - 1) / 3600} hours")
+            steps = len(loader) if args.max_steps is None else min(len(loader), args.max_steps)
+            print(f"epoch {epoch} used {dt}, mean loss {mean_loss}, left {dt * (cfg.TRAIN.END_EPOCH - epoch - 1) / 3600} hours, "
+                  f"{steps * cfg.TRAIN.BATCH_SIZE * world / max(dt, 1e-9):.2f} samples/s (files -> ingest -> train step)")
         save_checkpoint(checkpoint_dict(model, optimizer, lr_scheduler, epoch),
                         os.path.join(save_model_dir, f"NlosPose_final_dict_{epoch}.pth"))
     if rank == 0:
