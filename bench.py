@@ -324,6 +324,11 @@ def bench_highres(args):
     lct_ms = sum(v[1] for k, v in prof.items() if k.startswith("lct_"))
     lct_calls = 2 * args.steps  # forward + backward per step
     ach = 40.0 * V * B * lct_calls / (lct_ms / 1e3) / 1e9 if lct_ms else None
+    # bytes the five passes actually move per direction: a lone volume (Hermitian route) 136 V, a packed pair 272 V
+    moved = (136.0 * (B % 2) + 272.0 * (B // 2)) * V
+    ach_moved = moved * lct_calls / (lct_ms / 1e3) / 1e9 if lct_ms else None
+    conv_ms = sum(v[1] for k, v in prof.items() if k.startswith("dconv3_")) / args.steps
+    conv_gflop = 3 * 410.0 * B   # FE + U-Net convolutions forward 410.0 GFLOP at 1024 x 256 x 256; backward = 2x
     print(json.dumps({
         "metric": "samples/sec (256x256x1024 meas) FE+LCT+normalize+UNet fwd+bwd", "value": round(B * args.steps / dt, 3),
         "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -334,7 +339,12 @@ def bench_highres(args):
         "roofline": {"kernel": "lct (5 passes, forward or adjoint)", "bound": "hbm", "achieved": round(ach, 1) if ach else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4) if ach else None, "traffic": None,
                      "algorithmic_bytes": "40 * T*N*N per volume and direction (SURVEY 8d)",
-                     "ms_per_direction": round(lct_ms / lct_calls, 3) if lct_ms else None}}), flush=True)
+                     "moved_bytes_per_direction": moved, "achieved_on_moved_bytes": round(ach_moved, 1) if ach_moved else None,
+                     "frac_on_moved_bytes": round(ach_moved / HBM_PEAK_GBS, 4) if ach_moved else None,
+                     "ms_per_direction": round(lct_ms / lct_calls, 3) if lct_ms else None},
+        "thin_channel_convolutions": {"ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": conv_gflop,
+                                      "achieved_tflops": round(conv_gflop / conv_ms, 1) if conv_ms else None,
+                                      "peak_tflops": MFMA_F32_PEAK_TFLOPS}}), flush=True)
 
 
 def quick_native(args, local, note):
@@ -479,8 +489,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    losses = []
     for _ in range(args.steps):
         loss, _, _ = step()
+        losses.append(loss)          # device scalars: read back after the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -520,6 +532,8 @@ def main():
                                                       f"{args.bucket_mb:g} MB buckets)" if reducer is not None else ""), "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
                        "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
             "loss": round(float(loss.item()), 6),
+            # the same synthetic batch every step, Adam lr 1e-3 from the reference's initialisation: the loss must move
+            "loss_per_timed_step": [round(float(v.item()), 4) for v in losses],
         }
         roof = None
         if prof:
