@@ -1282,6 +1282,145 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_full(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------- stem weight gradient on the bf16 matrix cores
+// The same decomposition as k_stem_wgrad_full (one workgroup holds the whole 64 x 352 gradient, dZ is read once, the
+// tap operand comes straight from the input patch in LDS) for the bf16 modes: v_mfma_f32_32x32x16_bf16 takes 16 voxels
+// per instruction, 8 consecutive ones per lane.  A = dZ^T: the tile is staged [voxel][channel] as it lies in memory and
+// read through ds_read_b64_tr_b16 (as in k_wgrad).  B[voxel][tap] = x[voxel + tap]: the 8 consecutive voxels of a lane
+// are the 8-voxel x-run of one (z, y) row of the 4 x 4 x 8 tile, i.e. 8 consecutive bf16 of the patch starting at
+// an arbitrary element -- the patch is therefore kept in FOUR copies shifted by 0..3 elements, so that every run is two
+// 8-byte-aligned ds_read_b64 of copy (start & 3).  Patch pitches 28 / 281 keep those reads at <= 2 lanes per bank.
+// Operands are rounded to bf16 on their way into LDS, accumulation is fp32.
+constexpr int SWH_PR = 28, SWH_PP = 281, SWH_COPY = 738 * 4 /* bf16 per copy: 736 + 2 quad-words, the bank shift between copies */, SWH_LDT = 96;
+
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad_bf16(const float* __restrict__ X, const float* __restrict__ dZ,
+                                                            float* __restrict__ dW, int D, int H, int W, int pz, int py,
+                                                            int px, long tiles_total, int tiles_per_wg, int kpad) {
+  __shared__ __attribute__((aligned(16))) __bf16 Yh[SP_M * SWH_LDT];
+  __shared__ __attribute__((aligned(16))) __bf16 patch[4 * SWH_COPY + 16];   // last 16: zeros for invalid taps
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  // this wave's tap tiles: wave, wave + 4, wave + 8 (11 tiles of 32 taps cover 352 >= 343)
+  int toff[3];
+  bool tval[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tap = 32 * (wave + 4 * j) + col;
+    tval[j] = wave + 4 * j < 11 && tap < 343;
+    const int a = tap / 49, bb = (tap / 7) % 7, c = tap % 7;
+    toff[j] = tval[j] ? a * SWH_PP + bb * SWH_PR + c : 0;
+  }
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (tid < 16) patch[4 * SWH_COPY + tid] = (__bf16)0.f;
+
+  const long t0 = (long)blockIdx.x * tiles_per_wg, t1 = min(tiles_total, t0 + tiles_per_wg);
+  // tile t+1 is fetched into registers while tile t is multiplied
+  float4 zreg[SP_M / 16];
+  float preg[6];
+  const int zq = tid & 15, zr0 = tid >> 4;
+  auto fetch = [&](long t) {
+    long r_ = t;
+    const int bx = (int)(r_ % px);
+    r_ /= px;
+    const int by = (int)(r_ % py);
+    r_ /= py;
+    const int bz = (int)(r_ % pz);
+    const int b = (int)(r_ / pz);
+    const int z0 = bz * SP_Z, y0 = by * SP_Y, x0 = bx * SP_X;
+#pragma unroll
+    for (int pss = 0; pss < SP_M / 16; ++pss) {  // dZ tile: 128 voxels x 64 channels
+      const int r = zr0 + 16 * pss;
+      const int z = z0 + (r >> 5), y = y0 + ((r >> 3) & 3), x = x0 + (r & 7);
+      zreg[pss] = (z < D && y < H && x < W) ? *(const float4*)(dZ + ((((long)b * D + z) * H + y) * W + x) * 64 + zq * 4)
+                                           : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // input patch with its 3-voxel halo
+      const int e = tid + 256 * k;
+      const int pzz = e / 140, rem = e - pzz * 140, pyy = rem / 14, pxx = rem - pyy * 14;
+      const int z = z0 + pzz - 3, y = y0 + pyy - 3, x = x0 + pxx - 3;
+      preg[k] = (e < 1400 && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    ? X[(((long)b * D + z) * H + y) * W + x]
+                    : 0.f;
+    }
+  };
+  // fragment addressing of the transposing read (see k_wgrad): 16-lane group gq -> voxels 8*(gq>>1).., channels 16*(gq&1)..
+  const int gq = lane >> 4, li = lane & 15;
+  const int trow = 8 * (gq >> 1) + (li >> 2), tcol = 16 * (gq & 1) + 4 * (li & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  auto tr8 = [&](const __bf16* base) -> bf16x8 {
+    union {
+      s16x4 h[2];
+      bf16x8 f;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * SWH_LDT));
+    return u.f;
+  };
+  if (t0 < t1) fetch(t0);
+  for (long t = t0; t < t1; ++t) {
+    __syncthreads();  // previous tile's fragment reads are done
+#pragma unroll
+    for (int pss = 0; pss < SP_M / 16; ++pss) *(bf16x4*)(Yh + (zr0 + 16 * pss) * SWH_LDT + zq * 4) = to_bf16x4(zreg[pss]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int e = tid + 256 * k;
+      const int pzz = e / 140, rem = e - pzz * 140, pyy = rem / 14, pxx = rem - pyy * 14;
+      if (e < 1400) {
+        const int pi = pzz * SWH_PP + pyy * SWH_PR + pxx;
+        const __bf16 v = (__bf16)preg[k];
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft)
+          if (pi - sft >= 0) patch[sft * SWH_COPY + pi - sft] = v;   // copy s holds element i + s at index i
+      }
+    }
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);
+#pragma unroll 2
+    for (int ks = 0; ks < SP_M / 16; ++ks) {
+      // K = 16 voxels: (z, y) rows 2 ks and 2 ks + 1 of the tile, 8 voxels along x each; this lane's row:
+      const int rr = 2 * ks + half;
+      const int vbase = (rr >> 2) * SWH_PP + (rr & 3) * SWH_PR;
+      bf16x8 ha[2], hb[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ha[i] = tr8(Yh + (ks * 16 + trow) * SWH_LDT + i * 32 + tcol);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int e = vbase + toff[j];
+        const __bf16* src = tval[j] ? patch + (e & 3) * SWH_COPY + (e & ~3) : patch + 4 * SWH_COPY;
+        union {
+          uint2 q[2];
+          bf16x8 f;
+        } u;
+        u.q[0] = *(const uint2*)(src);
+        u.q[1] = *(const uint2*)(src + 4);
+        hb[j] = u.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (wave + 4 * j >= 11) continue;
+    const int tap = 32 * (wave + 4 * j) + col;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (tap < 343) atomicAdd(dW + (long)co * kpad + tap, acc[i][j][r]);
+      }
+  }
+}
+
 // ---------------------------------------------------------------- stem forward on the 4x4x1 matrix-core instruction
 // The stem (1 -> 64 channels, 7^3 taps) as a GEMM has K = 343 taps of a single-channel volume: the generic kernel
 // gathers its A tile element by element.  With v_mfma_f32_4x4x1_16b_f32 (16 blocks of a 4x4 outer product; row i =
@@ -1807,13 +1946,13 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, c
   const IgemmGeom& g = p.wgrad;
   const int Kc = p.stem ? g.kpt * BK : g.Cin;
   HP_CHECK_HIP(hipMemsetAsync(dw_packed, 0, sizeof(float) * hp_conv3d_packed_weight_elems(d), st));
-  if (p.stem && p.planes == 0 && d->Cout == 64 && !dyh) {
+  if (p.stem && p.planes <= 1 && d->Cout == 64 && !dyh) {
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     const long tiles = (long)d->B * pz * py * px;
     const int per_wg = (int)std::max<long>(1, (tiles + 1023) / 1024);  // ~1024 workgroups, 2 resident per CU
     HP_PROF("conv_wgrad", st);
-    hipLaunchKernelGGL(k_stem_wgrad_full, dim3((unsigned)((tiles + per_wg - 1) / per_wg)), dim3(256), 0, st, (const float*)x,
-                       (const float*)dy, dw_packed, d->Di,
+    hipLaunchKernelGGL(p.planes == 1 ? k_stem_wgrad_bf16 : k_stem_wgrad_full, dim3((unsigned)((tiles + per_wg - 1) / per_wg)), dim3(256),
+                       0, st, (const float*)x, (const float*)dy, dw_packed, d->Di,
                        d->Hi, d->Wi, pz, py, px, tiles, per_wg, Kc);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;

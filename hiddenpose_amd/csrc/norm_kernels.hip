@@ -5,12 +5,71 @@
 // one fp64 atomic per channel per block.
 #include <algorithm>
 #include <cstdint>
+#include <initializer_list>
 
 #include "hp_internal.h"
 
 namespace hp {
 
 constexpr int ET = 256;
+
+// Element-type plumbing of the BatchNorm passes.  IOM = 0: every tensor fp32, IOM = 1: every tensor bf16 -- both known
+// at compile time, so a pass issues all its loads back to back (a run-time type test per access put a conversion, and
+// with it a wait, between consecutive loads: the bf16 reduce pass ran SLOWER than the fp32 one) -- and a lane moves
+// 16 bytes either way: one channel quad of fp32 or two of bf16 (Q).  IOM = 2: mixed types, run-time flags, one quad.
+template <int IOM>
+struct QIO {
+  static constexpr int Q = IOM == 1 ? 2 : 1;
+  static __device__ __forceinline__ void ld(const void* p, long g, int half, float4 (&o)[Q]) {  // group g = quads g*Q ..
+    if constexpr (IOM == 0) {
+      o[0] = *(reinterpret_cast<const float4*>(p) + g);
+    } else if constexpr (IOM == 1) {
+      const uint4 u = *(reinterpret_cast<const uint4*>(p) + g);
+      o[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                         __uint_as_float(u.y & 0xffff0000u));
+      o[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                         __uint_as_float(u.w & 0xffff0000u));
+    } else {
+      o[0] = hp_ld4(p, 4 * g, half);
+    }
+  }
+  static __device__ __forceinline__ void st(void* p, long g, const float4 (&v)[Q], int half) {
+    if constexpr (IOM == 0) {
+      *(reinterpret_cast<float4*>(p) + g) = v[0];
+    } else if constexpr (IOM == 1) {
+      typedef __attribute__((ext_vector_type(2))) float f2;
+      typedef __attribute__((ext_vector_type(2))) __bf16 h2;
+      const h2 a = __builtin_convertvector((f2){v[0].x, v[0].y}, h2), b = __builtin_convertvector((f2){v[0].z, v[0].w}, h2);
+      const h2 c = __builtin_convertvector((f2){v[1].x, v[1].y}, h2), d = __builtin_convertvector((f2){v[1].z, v[1].w}, h2);
+      *(reinterpret_cast<uint4*>(p) + g) = make_uint4(__builtin_bit_cast(unsigned int, a), __builtin_bit_cast(unsigned int, b),
+                                                      __builtin_bit_cast(unsigned int, c), __builtin_bit_cast(unsigned int, d));
+    } else {
+      hp_st4(p, 4 * g, v[0], half);
+    }
+  }
+  // byte-per-quad masks of group g
+  static __device__ __forceinline__ unsigned ldm(const unsigned char* m, long g) {
+    if constexpr (Q == 2) return *(reinterpret_cast<const unsigned short*>(m) + g);
+    else return m[g];
+  }
+  static __device__ __forceinline__ void stm(unsigned char* m, long g, unsigned v) {
+    if constexpr (Q == 2) *(reinterpret_cast<unsigned short*>(m) + g) = (unsigned short)v;
+    else m[g] = (unsigned char)v;
+  }
+};
+__device__ __forceinline__ float4 f4_fma(float4 v, float4 a, float4 b) {
+  return make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+}
+__device__ __forceinline__ float4 f4_mask(float4 g, unsigned mk) {
+  return make_float4((mk & 1u) ? g.x : 0.f, (mk & 2u) ? g.y : 0.f, (mk & 4u) ? g.z : 0.f, (mk & 8u) ? g.w : 0.f);
+}
+__device__ __forceinline__ float4 f4_gate(float4 g, float4 y) {
+  return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+}
+// dz = a g + b z + c
+__device__ __forceinline__ float4 f4_dz(float4 g, float4 v, float4 a, float4 b, float4 k) {
+  return make_float4(a.x * g.x + b.x * v.x + k.x, a.y * g.y + b.y * v.y + k.y, a.z * g.z + b.z * v.z + k.z, a.w * g.w + b.w * v.w + k.w);
+}
 
 // stats[0:C] = sum, stats[C:2C] = sum of squares (fp64) over M rows
 __global__ void k_bn_finalize(const double* __restrict__ stats, long M, int C, float eps, float momentum,
@@ -40,6 +99,7 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 }
 
 // y = act((z - mean) * rstd * gamma + beta [+ res])
+template <int IOM>
 __global__ __launch_bounds__(ET) void k_bn_apply(const void* __restrict__ z, int z_half, const void* __restrict__ res, int res_half,
                                                  void* __restrict__ y, int y_half, long n4, int C4, const float4* __restrict__ mean,
                                                  const float4* __restrict__ rstd, const float4* __restrict__ gamma,
@@ -47,141 +107,162 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const void* __restrict__ z, int
                                                  unsigned char* __restrict__ mask_out, const float4* __restrict__ rmean,
                                                  const float4* __restrict__ rrstd, const float4* __restrict__ rgamma,
                                                  const float4* __restrict__ rbeta) {
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    const float4 v = hp_ld4(z, 4 * i, z_half), m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
-    // y = z * sc + sh with sc = rstd * gamma, sh = beta - mean * sc: the backward rebuilds the ReLU mask with
-    // exactly this expression
-    const float4 sc = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
-    const float4 sh = make_float4(b.x - m.x * sc.x, b.y - m.y * sc.y, b.z - m.z * sc.z, b.w - m.w * sc.w);
-    float4 o;
-    o.x = fmaf(v.x, sc.x, sh.x);
-    o.y = fmaf(v.y, sc.y, sh.y);
-    o.z = fmaf(v.z, sc.z, sh.z);
-    o.w = fmaf(v.w, sc.w, sh.w);
-    if (res) {
-      float4 q = hp_ld4(res, 4 * i, res_half);
-      if (rmean) {  // the residual is a raw convolution output with a BatchNorm of its own still to be applied
-        const float4 m2 = rmean[c], r2 = rrstd[c], g2 = rgamma[c], b2 = rbeta[c];
-        const float4 sc2 = make_float4(r2.x * g2.x, r2.y * g2.y, r2.z * g2.z, r2.w * g2.w);
-        const float4 sh2 = make_float4(b2.x - m2.x * sc2.x, b2.y - m2.y * sc2.y, b2.z - m2.z * sc2.z, b2.w - m2.w * sc2.w);
-        q = make_float4(fmaf(q.x, sc2.x, sh2.x), fmaf(q.y, sc2.y, sh2.y), fmaf(q.z, sc2.z, sh2.z), fmaf(q.w, sc2.w, sh2.w));
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  const long ng = n4 / Q;
+  const int CG = C4 / Q;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
+    const int c0 = (int)(i % CG) * Q;
+    float4 v[Q], q[Q], o[Q];
+    IO::ld(z, i, z_half, v);
+    if (res) IO::ld(res, i, res_half, q);
+    unsigned mk = 0u;
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const int c = c0 + e;
+      const float4 m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
+      // y = z * sc + sh with sc = rstd * gamma, sh = beta - mean * sc: the backward rebuilds the ReLU mask with
+      // exactly this expression
+      const float4 sc = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
+      const float4 sh = make_float4(b.x - m.x * sc.x, b.y - m.y * sc.y, b.z - m.z * sc.z, b.w - m.w * sc.w);
+      o[e] = f4_fma(v[e], sc, sh);
+      if (res) {
+        float4 qq = q[e];
+        if (rmean) {  // the residual is a raw convolution output with a BatchNorm of its own still to be applied
+          const float4 m2 = rmean[c], r2 = rrstd[c], g2 = rgamma[c], b2 = rbeta[c];
+          const float4 sc2 = make_float4(r2.x * g2.x, r2.y * g2.y, r2.z * g2.z, r2.w * g2.w);
+          const float4 sh2 = make_float4(b2.x - m2.x * sc2.x, b2.y - m2.y * sc2.y, b2.z - m2.z * sc2.z, b2.w - m2.w * sc2.w);
+          qq = f4_fma(qq, sc2, sh2);
+        }
+        o[e].x += qq.x;
+        o[e].y += qq.y;
+        o[e].z += qq.z;
+        o[e].w += qq.w;
       }
-      o.x += q.x;
-      o.y += q.y;
-      o.z += q.z;
-      o.w += q.w;
+      if (relu) o[e] = make_float4(fmaxf(o[e].x, 0.f), fmaxf(o[e].y, 0.f), fmaxf(o[e].z, 0.f), fmaxf(o[e].w, 0.f));
+      // one byte per channel quad: which outputs are positive (the backward reads this instead of y: 1 B, not 16)
+      mk |= (unsigned)((o[e].x > 0.f ? 1 : 0) | (o[e].y > 0.f ? 2 : 0) | (o[e].z > 0.f ? 4 : 0) | (o[e].w > 0.f ? 8 : 0)) << (8 * e);
     }
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f);
-      o.y = fmaxf(o.y, 0.f);
-      o.z = fmaxf(o.z, 0.f);
-      o.w = fmaxf(o.w, 0.f);
-    }
-    hp_st4(y, 4 * i, o, y_half);
-    // one byte per channel quad: which outputs are positive (the backward reads this instead of y: 1 B, not 16)
-    if (mask_out)
-      mask_out[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+    IO::st(y, i, o, y_half);
+    if (mask_out) IO::stm(mask_out, i, mk);
   }
 }
 
 // Pass 1 of the backward: g = dy * [y > 0] (written to g_out), per channel sum(g) and
 // sum(g * zhat) into red[0:C], red[C:2C] (fp64).  Thread t owns channel quad (t % C4) --
 // the block strides over rows so that a thread always sees the same channels.
-template <int UNR>
+template <int UNR, int IOM>
 __global__ __launch_bounds__(ET) void k_bn_bwd_reduce(const void* __restrict__ dy, int dy_half, const float4* __restrict__ y,
                                                       const void* __restrict__ z, int z_half, void* __restrict__ g_out, int g_half, long M,
                                                       int C4, const float4* __restrict__ mean,
                                                       const float4* __restrict__ rstd, int relu,
                                                       double* __restrict__ red, const float4* __restrict__ gamma,
                                                       const float4* __restrict__ beta, const unsigned char* __restrict__ mask) {
-  __shared__ float4 ssum[ET], sdot[ET];
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  __shared__ float4 ssum[Q][ET], sdot[Q][ET];
   const int tid = threadIdx.x;
-  const int lanes_per_row = C4 < ET ? C4 : ET;       // threads covering one row pass
-  const int rows_per_pass = ET / lanes_per_row;      // >= 1 when C4 <= ET
-  const int cq_passes = (C4 + ET - 1) / ET;          // > 1 when C4 > ET
-  const int my_row = tid / lanes_per_row, my_cq0 = tid % lanes_per_row;
-  for (int cp = 0; cp < cq_passes; ++cp) {
-    const int cq = my_cq0 + cp * ET;
-    float4 s = make_float4(0, 0, 0, 0), d = make_float4(0, 0, 0, 0);
-    if (cq < C4 && my_row < rows_per_pass) {
-      const float4 m = mean[cq], r = rstd[cq];
-      // without a residual the ReLU mask follows from z alone: the forward output need not be read
-      float4 sc = make_float4(0, 0, 0, 0), sh = sc;
-      if (relu && !y) {
-        const float4 ga = gamma[cq], be = beta[cq];
-        sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
-        sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
+  const int CG = C4 / Q;                             // channel groups (Q quads each) per row
+  const int lanes_per_row = CG < ET ? CG : ET;       // threads covering one row pass
+  const int rows_per_pass = ET / lanes_per_row;      // >= 1 when CG <= ET
+  const int cg_passes = (CG + ET - 1) / ET;          // > 1 when CG > ET
+  const int my_row = tid / lanes_per_row, my_cg0 = tid % lanes_per_row;
+  for (int cp = 0; cp < cg_passes; ++cp) {
+    const int cg = my_cg0 + cp * ET;
+    float4 s[Q], d[Q];
+#pragma unroll
+    for (int e = 0; e < Q; ++e) s[e] = d[e] = make_float4(0, 0, 0, 0);
+    if (cg < CG && my_row < rows_per_pass) {
+      float4 m[Q], r[Q], sc[Q], sh[Q];
+#pragma unroll
+      for (int e = 0; e < Q; ++e) {
+        m[e] = mean[cg * Q + e];
+        r[e] = rstd[cg * Q + e];
+        // without a residual the ReLU mask follows from z alone: the forward output need not be read
+        sc[e] = sh[e] = make_float4(0, 0, 0, 0);
+        if (relu && !y) {
+          const float4 ga = gamma[cg * Q + e], be = beta[cg * Q + e];
+          sc[e] = make_float4(r[e].x * ga.x, r[e].y * ga.y, r[e].z * ga.z, r[e].w * ga.w);
+          sh[e] = make_float4(be.x - m[e].x * sc[e].x, be.y - m[e].y * sc[e].y, be.z - m[e].z * sc[e].z, be.w - m[e].w * sc[e].w);
+        }
       }
       // UNR rows per trip: all their loads are issued before the first use (the pass is a pure read stream and
       // needs ~15 MB in flight chip-wide to run at HBM speed; one row per trip keeps ~6 MB in flight)
-      // (bf16 tensors: 8 rows per trip, the same bytes in flight as 4 rows of fp32)
       const long stride = (long)gridDim.x * rows_per_pass;
       for (long row0 = (long)blockIdx.x * rows_per_pass + my_row; row0 < M; row0 += UNR * stride) {
-        float4 gq[UNR], vq[UNR], yq[UNR];
+        float4 gq[UNR][Q], vq[UNR][Q], yq[UNR];
         unsigned mq[UNR];
         bool okq[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const long row = row0 + u * stride;
           okq[u] = row < M;
-          const long i = (okq[u] ? row : row0) * C4 + cq;
-          gq[u] = hp_ld4(dy, 4 * i, dy_half);
-          vq[u] = hp_ld4(z, 4 * i, z_half);
-          mq[u] = (relu && mask) ? mask[i] : 0u;
-          yq[u] = (relu && !mask && y) ? y[i] : make_float4(0, 0, 0, 0);
+          const long i = (okq[u] ? row : row0) * CG + cg;
+          IO::ld(dy, i, dy_half, gq[u]);
+          IO::ld(z, i, z_half, vq[u]);
+          mq[u] = (relu && mask) ? IO::ldm(mask, i) : 0u;
+          if constexpr (Q == 1) yq[u] = (relu && !mask && y) ? y[i] : make_float4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           if (!okq[u]) continue;
-          const long i = (row0 + u * stride) * C4 + cq;
-          float4 g = gq[u];
-          const float4 v = vq[u];
-          if (relu && mask) {
-            const unsigned mk = mq[u];
-            g.x = (mk & 1u) ? g.x : 0.f;
-            g.y = (mk & 2u) ? g.y : 0.f;
-            g.z = (mk & 4u) ? g.z : 0.f;
-            g.w = (mk & 8u) ? g.w : 0.f;
-          } else if (relu) {
-            float4 yy;
-            if (y) yy = yq[u];
-            else yy = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-            g.x = yy.x > 0.f ? g.x : 0.f;
-            g.y = yy.y > 0.f ? g.y : 0.f;
-            g.z = yy.z > 0.f ? g.z : 0.f;
-            g.w = yy.w > 0.f ? g.w : 0.f;
+          const long i = (row0 + u * stride) * CG + cg;
+          float4 g[Q];
+#pragma unroll
+          for (int e = 0; e < Q; ++e) {
+            g[e] = gq[u][e];
+            const float4 v = vq[u][e];
+            if (relu && mask) {
+              g[e] = f4_mask(g[e], mq[u] >> (8 * e));
+            } else if (relu) {
+              float4 yy;
+              if constexpr (Q == 1) {
+                if (y) yy = yq[u];
+                else yy = f4_fma(v, sc[e], sh[e]);
+              } else {
+                yy = f4_fma(v, sc[e], sh[e]);
+              }
+              g[e] = f4_gate(g[e], yy);
+            }
+            s[e].x += g[e].x;
+            s[e].y += g[e].y;
+            s[e].z += g[e].z;
+            s[e].w += g[e].w;
+            d[e].x += g[e].x * (v.x - m[e].x) * r[e].x;
+            d[e].y += g[e].y * (v.y - m[e].y) * r[e].y;
+            d[e].z += g[e].z * (v.z - m[e].z) * r[e].z;
+            d[e].w += g[e].w * (v.w - m[e].w) * r[e].w;
           }
-          if (g_out) hp_st4(g_out, 4 * i, g, g_half);
-          s.x += g.x;
-          s.y += g.y;
-          s.z += g.z;
-          s.w += g.w;
-          d.x += g.x * (v.x - m.x) * r.x;
-          d.y += g.y * (v.y - m.y) * r.y;
-          d.z += g.z * (v.z - m.z) * r.z;
-          d.w += g.w * (v.w - m.w) * r.w;
+          if (g_out) IO::st(g_out, i, g, g_half);
         }
       }
     }
-    ssum[tid] = s;
-    sdot[tid] = d;
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      ssum[e][tid] = s[e];
+      sdot[e][tid] = d[e];
+    }
     __syncthreads();
-    if (my_row == 0 && cq < C4) {
-      for (int rr = 1; rr < rows_per_pass; ++rr) {
-        const float4 a = ssum[rr * lanes_per_row + my_cq0], b = sdot[rr * lanes_per_row + my_cq0];
-        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-        d.x += b.x; d.y += b.y; d.z += b.z; d.w += b.w;
-      }
+    if (my_row == 0 && cg < CG) {
       const int C = C4 * 4;
-      atomicAdd(red + cq * 4 + 0, (double)s.x);
-      atomicAdd(red + cq * 4 + 1, (double)s.y);
-      atomicAdd(red + cq * 4 + 2, (double)s.z);
-      atomicAdd(red + cq * 4 + 3, (double)s.w);
-      atomicAdd(red + C + cq * 4 + 0, (double)d.x);
-      atomicAdd(red + C + cq * 4 + 1, (double)d.y);
-      atomicAdd(red + C + cq * 4 + 2, (double)d.z);
-      atomicAdd(red + C + cq * 4 + 3, (double)d.w);
+#pragma unroll
+      for (int e = 0; e < Q; ++e) {
+        float4 ss = s[e], dd = d[e];
+        for (int rr = 1; rr < rows_per_pass; ++rr) {
+          const float4 a = ssum[e][rr * lanes_per_row + my_cg0], b = sdot[e][rr * lanes_per_row + my_cg0];
+          ss.x += a.x; ss.y += a.y; ss.z += a.z; ss.w += a.w;
+          dd.x += b.x; dd.y += b.y; dd.z += b.z; dd.w += b.w;
+        }
+        const int cq = cg * Q + e;
+        atomicAdd(red + cq * 4 + 0, (double)ss.x);
+        atomicAdd(red + cq * 4 + 1, (double)ss.y);
+        atomicAdd(red + cq * 4 + 2, (double)ss.z);
+        atomicAdd(red + cq * 4 + 3, (double)ss.w);
+        atomicAdd(red + C + cq * 4 + 0, (double)dd.x);
+        atomicAdd(red + C + cq * 4 + 1, (double)dd.y);
+        atomicAdd(red + C + cq * 4 + 2, (double)dd.z);
+        atomicAdd(red + C + cq * 4 + 3, (double)dd.w);
+      }
     }
     __syncthreads();
   }
@@ -211,162 +292,205 @@ __global__ void k_bn_bwd_coef(const double* __restrict__ red, long M, int C, con
   }
 }
 
+template <int IOM>
 __global__ __launch_bounds__(ET) void k_bn_bwd_apply(const void* __restrict__ g, int g_half, const void* __restrict__ z, int z_half,
                                                      void* __restrict__ dz, int dz_half, long n4, int C4,
                                                      const float4* __restrict__ ca, const float4* __restrict__ cb,
                                                      const float4* __restrict__ cc) {
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    const float4 gg = hp_ld4(g, 4 * i, g_half), v = hp_ld4(z, 4 * i, z_half), a = ca[c], b = cb[c], k = cc[c];
-    float4 o;
-    o.x = a.x * gg.x + b.x * v.x + k.x;
-    o.y = a.y * gg.y + b.y * v.y + k.y;
-    o.z = a.z * gg.z + b.z * v.z + k.z;
-    o.w = a.w * gg.w + b.w * v.w + k.w;
-    hp_st4(dz, 4 * i, o, dz_half);
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  const long ng = n4 / Q;
+  const int CG = C4 / Q;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
+    const int c0 = (int)(i % CG) * Q;
+    float4 gg[Q], v[Q], o[Q];
+    IO::ld(g, i, g_half, gg);
+    IO::ld(z, i, z_half, v);
+#pragma unroll
+    for (int e = 0; e < Q; ++e) o[e] = f4_dz(gg[e], v[e], ca[c0 + e], cb[c0 + e], cc[c0 + e]);
+    IO::st(dz, i, o, dz_half);
   }
 }
 
 // Pass 2 for units without a residual: the masked gradient is not parked in memory by pass 1; the ReLU mask is
 // rebuilt here from z (the same affine map, bit for bit), so the unit's backward moves 5 tensors instead of 6.
+template <int IOM>
 __global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const void* __restrict__ dy, int dy_half, const void* __restrict__ z, int z_half,
                                                           void* __restrict__ dz, int dz_half, long n4, int C4,
                                                           const float4* __restrict__ ca, const float4* __restrict__ cb,
                                                           const float4* __restrict__ cc, const float4* __restrict__ mean,
                                                           const float4* __restrict__ rstd, const float4* __restrict__ gamma,
                                                           const float4* __restrict__ beta, int relu) {
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    float4 gg = hp_ld4(dy, 4 * i, dy_half);
-    const float4 v = hp_ld4(z, 4 * i, z_half), a = ca[c], b = cb[c], k = cc[c];
-    if (relu) {
-      const float4 m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
-      const float4 sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
-      const float4 sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
-      gg.x = fmaf(v.x, sc.x, sh.x) > 0.f ? gg.x : 0.f;
-      gg.y = fmaf(v.y, sc.y, sh.y) > 0.f ? gg.y : 0.f;
-      gg.z = fmaf(v.z, sc.z, sh.z) > 0.f ? gg.z : 0.f;
-      gg.w = fmaf(v.w, sc.w, sh.w) > 0.f ? gg.w : 0.f;
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  const long ng = n4 / Q;
+  const int CG = C4 / Q;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
+    const int c0 = (int)(i % CG) * Q;
+    float4 gg[Q], v[Q], o[Q];
+    IO::ld(dy, i, dy_half, gg);
+    IO::ld(z, i, z_half, v);
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const int c = c0 + e;
+      if (relu) {
+        const float4 m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+        const float4 sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
+        const float4 sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
+        gg[e] = f4_gate(gg[e], f4_fma(v[e], sc, sh));
+      }
+      o[e] = f4_dz(gg[e], v[e], ca[c], cb[c], cc[c]);
     }
-    float4 o;
-    o.x = a.x * gg.x + b.x * v.x + k.x;
-    o.y = a.y * gg.y + b.y * v.y + k.y;
-    o.z = a.z * gg.z + b.z * v.z + k.z;
-    o.w = a.w * gg.w + b.w * v.w + k.w;
-    hp_st4(dz, 4 * i, o, dz_half);
+    IO::st(dz, i, o, dz_half);
   }
 }
 
 // Pass 2 for units whose ReLU mask is the byte mask of the forward apply (units with a residual, or a shortcut unit
 // fed by such a unit's output gradient): g = dy (.) mask is rebuilt from the byte instead of being parked by pass 1,
 // so neither this unit nor the consumer of the shortcut gradient moves a masked copy of dy through memory.
+template <int IOM>
 __global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const void* __restrict__ dy, int dy_half, const void* __restrict__ z, int z_half,
                                                               void* __restrict__ dz, int dz_half, long n4, int C4,
                                                               const float4* __restrict__ ca, const float4* __restrict__ cb,
                                                               const float4* __restrict__ cc,
                                                               const unsigned char* __restrict__ mask) {
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    float4 gg = hp_ld4(dy, 4 * i, dy_half);
-    const unsigned mk = mask[i];
-    const float4 v = hp_ld4(z, 4 * i, z_half), a = ca[c], b = cb[c], k = cc[c];
-    gg.x = (mk & 1u) ? gg.x : 0.f;
-    gg.y = (mk & 2u) ? gg.y : 0.f;
-    gg.z = (mk & 4u) ? gg.z : 0.f;
-    gg.w = (mk & 8u) ? gg.w : 0.f;
-    float4 o;
-    o.x = a.x * gg.x + b.x * v.x + k.x;
-    o.y = a.y * gg.y + b.y * v.y + k.y;
-    o.z = a.z * gg.z + b.z * v.z + k.z;
-    o.w = a.w * gg.w + b.w * v.w + k.w;
-    hp_st4(dz, 4 * i, o, dz_half);
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  const long ng = n4 / Q;
+  const int CG = C4 / Q;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
+    const int c0 = (int)(i % CG) * Q;
+    float4 gg[Q], v[Q], o[Q];
+    IO::ld(dy, i, dy_half, gg);
+    const unsigned mk = IO::ldm(mask, i);
+    IO::ld(z, i, z_half, v);
+#pragma unroll
+    for (int e = 0; e < Q; ++e) o[e] = f4_dz(f4_mask(gg[e], mk >> (8 * e)), v[e], ca[c0 + e], cb[c0 + e], cc[c0 + e]);
+    IO::st(dz, i, o, dz_half);
   }
 }
 
 // ---- Two BatchNorm units that receive the same gradient g = dy (.) mask (Bottleneck with a shortcut convolution:
 // bn3 of the main branch and the shortcut's BatchNorm both feed the residual sum): one reduction and one apply pass
 // read dy and the byte mask once for both.  C4 <= ET is required (channel quads per row fit a workgroup pass).
+template <int IOM>
 __global__ __launch_bounds__(ET) void k_bn_bwd_reduce_dual(const void* __restrict__ dy, int dy_half, const unsigned char* __restrict__ mask,
                                                            const void* __restrict__ za, const void* __restrict__ zb, int z_half, long M,
                                                            int C4, const float4* __restrict__ mean_a,
                                                            const float4* __restrict__ rstd_a, const float4* __restrict__ mean_b,
                                                            const float4* __restrict__ rstd_b, double* __restrict__ red_a,
                                                            double* __restrict__ red_b) {
-  __shared__ float4 ssum[ET], sda[ET], sdb[ET];
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  constexpr int UNR = 2;
+  __shared__ float4 ssum[Q][ET], sda[Q][ET], sdb[Q][ET];
   const int tid = threadIdx.x;
-  const int rows_per_pass = ET / C4;
-  const int my_row = tid / C4, cq = tid % C4;
-  float4 s = make_float4(0, 0, 0, 0), da = s, db = s;
+  const int CG = C4 / Q;
+  const int rows_per_pass = ET / CG;
+  const int my_row = tid / CG, cg = tid % CG;
+  float4 s[Q], da[Q], db[Q];
+#pragma unroll
+  for (int e = 0; e < Q; ++e) s[e] = da[e] = db[e] = make_float4(0, 0, 0, 0);
   if (my_row < rows_per_pass) {
-    const float4 ma = mean_a[cq], ra = rstd_a[cq], mb = mean_b[cq], rb = rstd_b[cq];
-    for (long row = (long)blockIdx.x * rows_per_pass + my_row; row < M; row += (long)gridDim.x * rows_per_pass) {
-      const long i = row * C4 + cq;
-      float4 g = hp_ld4(dy, 4 * i, dy_half);
-      const unsigned mk = mask[i];
-      const float4 va = hp_ld4(za, 4 * i, z_half), vb = hp_ld4(zb, 4 * i, z_half);
-      g.x = (mk & 1u) ? g.x : 0.f;
-      g.y = (mk & 2u) ? g.y : 0.f;
-      g.z = (mk & 4u) ? g.z : 0.f;
-      g.w = (mk & 8u) ? g.w : 0.f;
-      s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
-      da.x += g.x * (va.x - ma.x) * ra.x;
-      da.y += g.y * (va.y - ma.y) * ra.y;
-      da.z += g.z * (va.z - ma.z) * ra.z;
-      da.w += g.w * (va.w - ma.w) * ra.w;
-      db.x += g.x * (vb.x - mb.x) * rb.x;
-      db.y += g.y * (vb.y - mb.y) * rb.y;
-      db.z += g.z * (vb.z - mb.z) * rb.z;
-      db.w += g.w * (vb.w - mb.w) * rb.w;
+    float4 ma[Q], ra[Q], mb[Q], rb[Q];
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      ma[e] = mean_a[cg * Q + e];
+      ra[e] = rstd_a[cg * Q + e];
+      mb[e] = mean_b[cg * Q + e];
+      rb[e] = rstd_b[cg * Q + e];
+    }
+    const long stride = (long)gridDim.x * rows_per_pass;
+    for (long row0 = (long)blockIdx.x * rows_per_pass + my_row; row0 < M; row0 += UNR * stride) {
+      float4 gq[UNR][Q], vaq[UNR][Q], vbq[UNR][Q];
+      unsigned mq[UNR];
+      bool okq[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long row = row0 + u * stride;
+        okq[u] = row < M;
+        const long i = (okq[u] ? row : row0) * CG + cg;
+        IO::ld(dy, i, dy_half, gq[u]);
+        mq[u] = IO::ldm(mask, i);
+        IO::ld(za, i, z_half, vaq[u]);
+        IO::ld(zb, i, z_half, vbq[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (!okq[u]) continue;
+#pragma unroll
+        for (int e = 0; e < Q; ++e) {
+          const float4 g = f4_mask(gq[u][e], mq[u] >> (8 * e)), va = vaq[u][e], vb = vbq[u][e];
+          s[e].x += g.x; s[e].y += g.y; s[e].z += g.z; s[e].w += g.w;
+          da[e].x += g.x * (va.x - ma[e].x) * ra[e].x;
+          da[e].y += g.y * (va.y - ma[e].y) * ra[e].y;
+          da[e].z += g.z * (va.z - ma[e].z) * ra[e].z;
+          da[e].w += g.w * (va.w - ma[e].w) * ra[e].w;
+          db[e].x += g.x * (vb.x - mb[e].x) * rb[e].x;
+          db[e].y += g.y * (vb.y - mb[e].y) * rb[e].y;
+          db[e].z += g.z * (vb.z - mb[e].z) * rb[e].z;
+          db[e].w += g.w * (vb.w - mb[e].w) * rb[e].w;
+        }
+      }
     }
   }
-  ssum[tid] = s;
-  sda[tid] = da;
-  sdb[tid] = db;
+#pragma unroll
+  for (int e = 0; e < Q; ++e) {
+    ssum[e][tid] = s[e];
+    sda[e][tid] = da[e];
+    sdb[e][tid] = db[e];
+  }
   __syncthreads();
   if (my_row == 0) {
-    for (int rr = 1; rr < rows_per_pass; ++rr) {
-      const float4 a = ssum[rr * C4 + cq], b = sda[rr * C4 + cq], c = sdb[rr * C4 + cq];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-      da.x += b.x; da.y += b.y; da.z += b.z; da.w += b.w;
-      db.x += c.x; db.y += c.y; db.z += c.z; db.w += c.w;
-    }
     const int C = C4 * 4;
-    const float sv[4] = {s.x, s.y, s.z, s.w}, av[4] = {da.x, da.y, da.z, da.w}, bv[4] = {db.x, db.y, db.z, db.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      atomicAdd(red_a + cq * 4 + e, (double)sv[e]);
-      atomicAdd(red_b + cq * 4 + e, (double)sv[e]);
-      atomicAdd(red_a + C + cq * 4 + e, (double)av[e]);
-      atomicAdd(red_b + C + cq * 4 + e, (double)bv[e]);
+    for (int e = 0; e < Q; ++e) {
+      float4 ss = s[e], aa = da[e], bb = db[e];
+      for (int rr = 1; rr < rows_per_pass; ++rr) {
+        const float4 a = ssum[e][rr * CG + cg], b = sda[e][rr * CG + cg], c = sdb[e][rr * CG + cg];
+        ss.x += a.x; ss.y += a.y; ss.z += a.z; ss.w += a.w;
+        aa.x += b.x; aa.y += b.y; aa.z += b.z; aa.w += b.w;
+        bb.x += c.x; bb.y += c.y; bb.z += c.z; bb.w += c.w;
+      }
+      const int cq = cg * Q + e;
+      const float sv[4] = {ss.x, ss.y, ss.z, ss.w}, av[4] = {aa.x, aa.y, aa.z, aa.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(red_a + cq * 4 + k, (double)sv[k]);
+        atomicAdd(red_b + cq * 4 + k, (double)sv[k]);
+        atomicAdd(red_a + C + cq * 4 + k, (double)av[k]);
+        atomicAdd(red_b + C + cq * 4 + k, (double)bv[k]);
+      }
     }
   }
 }
 
+template <int IOM>
 __global__ __launch_bounds__(ET) void k_bn_bwd_apply_dual(const void* __restrict__ dy, int dy_half, const unsigned char* __restrict__ mask,
                                                           const void* __restrict__ za, const void* __restrict__ zb, int z_half,
                                                           void* __restrict__ dza, void* __restrict__ dzb, int dz_half, long n4, int C4,
                                                           const float4* __restrict__ caa, const float4* __restrict__ cba,
                                                           const float4* __restrict__ cca, const float4* __restrict__ cab,
                                                           const float4* __restrict__ cbb, const float4* __restrict__ ccb) {
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) {
-    const int c = (int)(i % C4);
-    float4 gg = hp_ld4(dy, 4 * i, dy_half);
-    const unsigned mk = mask[i];
-    const float4 va = hp_ld4(za, 4 * i, z_half), vb = hp_ld4(zb, 4 * i, z_half);
-    gg.x = (mk & 1u) ? gg.x : 0.f;
-    gg.y = (mk & 2u) ? gg.y : 0.f;
-    gg.z = (mk & 4u) ? gg.z : 0.f;
-    gg.w = (mk & 8u) ? gg.w : 0.f;
-    {
-      const float4 a = caa[c], b = cba[c], k = cca[c];
-      hp_st4(dza, 4 * i, make_float4(a.x * gg.x + b.x * va.x + k.x, a.y * gg.y + b.y * va.y + k.y, a.z * gg.z + b.z * va.z + k.z,
-                                     a.w * gg.w + b.w * va.w + k.w), dz_half);
+  using IO = QIO<IOM>;
+  constexpr int Q = IO::Q;
+  const long ng = n4 / Q;
+  const int CG = C4 / Q;
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
+    const int c0 = (int)(i % CG) * Q;
+    float4 gg[Q], va[Q], vb[Q], oa[Q], ob[Q];
+    IO::ld(dy, i, dy_half, gg);
+    const unsigned mk = IO::ldm(mask, i);
+    IO::ld(za, i, z_half, va);
+    IO::ld(zb, i, z_half, vb);
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const float4 g = f4_mask(gg[e], mk >> (8 * e));
+      oa[e] = f4_dz(g, va[e], caa[c0 + e], cba[c0 + e], cca[c0 + e]);
+      ob[e] = f4_dz(g, vb[e], cab[c0 + e], cbb[c0 + e], ccb[c0 + e]);
     }
-    {
-      const float4 a = cab[c], b = cbb[c], k = ccb[c];
-      hp_st4(dzb, 4 * i, make_float4(a.x * gg.x + b.x * vb.x + k.x, a.y * gg.y + b.y * vb.y + k.y, a.z * gg.z + b.z * vb.z + k.z,
-                                     a.w * gg.w + b.w * vb.w + k.w), dz_half);
-    }
+    IO::st(dza, i, oa, dz_half);
+    IO::st(dzb, i, ob, dz_half);
   }
 }
 
@@ -791,6 +915,24 @@ static unsigned grid_for(long n, int per_block = ET) {
   return (unsigned)std::min<long>((n + per_block - 1) / per_block, 256 * 8);
 }
 
+// IOM of QIO for a call: 0 = every tensor fp32, 1 = every tensor bf16 (and an even number of channel quads), 2 = mixed
+static int io_mode(int C4, std::initializer_list<int> halves) {
+  int n = 0, h = 0;
+  for (int v : halves) {
+    ++n;
+    h += v ? 1 : 0;
+  }
+  if (h == 0) return 0;
+  return (h == n && C4 % 2 == 0) ? 1 : 2;
+}
+// launch KERN<IOM> for the run-time io mode `iom`
+#define HP_LAUNCH_IOM(KERN, iom, grid, st, ...)                                                      \
+  do {                                                                                              \
+    if ((iom) == 0) hipLaunchKernelGGL(KERN<0>, dim3(grid), dim3(ET), 0, st, __VA_ARGS__);          \
+    else if ((iom) == 1) hipLaunchKernelGGL(KERN<1>, dim3(grid), dim3(ET), 0, st, __VA_ARGS__);     \
+    else hipLaunchKernelGGL(KERN<2>, dim3(grid), dim3(ET), 0, st, __VA_ARGS__);                     \
+  } while (0)
+
 }  // namespace hp
 
 using namespace hp;
@@ -836,9 +978,11 @@ extern "C" int hp_bn_apply_res_bn(const void* z, const void* res, void* y, long 
   // io & HP_BN_ACT_BF16: y (and a plain residual, which is an activation too) are bf16; a residual that comes with its own
   // BatchNorm is the shortcut convolution's raw fp32 output
   const int act_half = (io & HP_BN_ACT_BF16) ? 1 : 0, z_half = (io & HP_BN_Z_BF16) ? 1 : 0;
-  hipLaunchKernelGGL(k_bn_apply, dim3(grid_for(n4)), dim3(ET), 0, st, z, z_half, res, res_mean ? z_half : act_half, y, act_half, n4,
-                     C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu, relu_mask,
-                     (const float4*)res_mean, (const float4*)res_rstd, (const float4*)res_gamma, (const float4*)res_beta);
+  const int res_half = res_mean ? z_half : act_half;
+  const int iom = res ? io_mode(C / 4, {z_half, act_half, res_half}) : io_mode(C / 4, {z_half, act_half});
+  HP_LAUNCH_IOM(k_bn_apply, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, z, z_half, res, res_half, y, act_half, n4,
+                C / 4, (const float4*)mean, (const float4*)rstd, (const float4*)gamma, (const float4*)beta, relu, relu_mask,
+                (const float4*)res_mean, (const float4*)res_rstd, (const float4*)res_gamma, (const float4*)res_beta);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
@@ -871,28 +1015,44 @@ extern "C" int hp_bn_backward(const void* dy, const float* y, const void* z, voi
   void* gbuf = (remask || bytemask) ? nullptr : g_out ? g_out : dz;
   {
     HP_PROF("bn_bwd_reduce", st);
-    const int rows_per_pass = C4 < ET ? ET / C4 : 1;
+    // the forward output y, where a caller still passes it, is fp32: such calls take the mixed path
+    const int iom = y ? (dy_half || z_half || (gbuf && dz_half) ? 2 : 0)
+                      : gbuf ? io_mode(C4, {dy_half, z_half, dz_half}) : io_mode(C4, {dy_half, z_half});
+    const int CG = C4 / (iom == 1 ? 2 : 1);
+    const int rows_per_pass = CG < ET ? ET / CG : 1;
     const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
-    auto* const kern = (dy_half && z_half) ? k_bn_bwd_reduce<8> : k_bn_bwd_reduce<4>;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half,
-                       gbuf, dz_half, M, C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma,
-                       (const float4*)beta_for_mask, relu_mask);
+    if (iom == 0)
+      hipLaunchKernelGGL((k_bn_bwd_reduce<4, 0>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
+                         C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma, (const float4*)beta_for_mask,
+                         relu_mask);
+    else if (iom == 1)
+      hipLaunchKernelGGL((k_bn_bwd_reduce<4, 1>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
+                         C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma, (const float4*)beta_for_mask,
+                         relu_mask);
+    else
+      hipLaunchKernelGGL((k_bn_bwd_reduce<4, 2>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
+                         C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma, (const float4*)beta_for_mask,
+                         relu_mask);
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, M, C, mean, rstd, gamma, train, dgamma,
                      dbeta, ca, cb, cc);
   {
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
-    if (bytemask)
-      hipLaunchKernelGGL(k_bn_bwd_apply_bytemask, dim3(grid_for(n4)), dim3(ET), 0, st, dy, dy_half, z, z_half,
-                         dz, dz_half, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
-    else if (remask)
-      hipLaunchKernelGGL(k_bn_bwd_apply_mask, dim3(grid_for(n4)), dim3(ET), 0, st, dy, dy_half, z, z_half,
-                         dz, dz_half, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean,
-                         (const float4*)rstd, (const float4*)gamma, (const float4*)beta_for_mask, relu);
-    else
-      hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(n4)), dim3(ET), 0, st, gbuf, dz_half, z, z_half,
-                         dz, dz_half, n4, C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
+    if (bytemask) {
+      const int iom = io_mode(C4, {dy_half, z_half, dz_half});
+      HP_LAUNCH_IOM(k_bn_bwd_apply_bytemask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+                    (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
+    } else if (remask) {
+      const int iom = io_mode(C4, {dy_half, z_half, dz_half});
+      HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+                    (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean, (const float4*)rstd,
+                    (const float4*)gamma, (const float4*)beta_for_mask, relu);
+    } else {
+      const int iom = io_mode(C4, {z_half, dz_half});
+      HP_LAUNCH_IOM(k_bn_bwd_apply, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, (const void*)gbuf, dz_half, z, z_half, dz, dz_half, n4,
+                    C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
+    }
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
@@ -918,10 +1078,11 @@ extern "C" int hp_bn_backward_dual(const void* dy, const unsigned char* relu_mas
   const int C4 = C / 4;
   {
     HP_PROF("bn_bwd_reduce", st);
-    const int rows_per_pass = ET / C4;
+    const int iom = io_mode(C4, {dy_half, z_half});
+    const int rows_per_pass = ET / (C4 / (iom == 1 ? 2 : 1));
     const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
-    hipLaunchKernelGGL(k_bn_bwd_reduce_dual, dim3(nb), dim3(ET), 0, st, dy, dy_half, relu_mask, z_a, z_b, z_half, M, C4, (const float4*)mean_a, (const float4*)rstd_a, (const float4*)mean_b,
-                       (const float4*)rstd_b, red_a, red_b);
+    HP_LAUNCH_IOM(k_bn_bwd_reduce_dual, iom, nb, st, dy, dy_half, relu_mask, z_a, z_b, z_half, M, C4, (const float4*)mean_a,
+                  (const float4*)rstd_a, (const float4*)mean_b, (const float4*)rstd_b, red_a, red_b);
   }
   hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red_a, M, C, mean_a, rstd_a, gamma_a, train_a,
                      dgamma_a, dbeta_a, ca_a, cb_a, cc_a);
@@ -930,9 +1091,10 @@ extern "C" int hp_bn_backward_dual(const void* dy, const unsigned char* relu_mas
   {
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
-    hipLaunchKernelGGL(k_bn_bwd_apply_dual, dim3(grid_for(n4)), dim3(ET), 0, st, dy, dy_half, relu_mask, z_a, z_b, z_half,
-                       dz_a, dz_b, dz_half, n4, C4, (const float4*)ca_a, (const float4*)cb_a,
-                       (const float4*)cc_a, (const float4*)ca_b, (const float4*)cb_b, (const float4*)cc_b);
+    const int iom = io_mode(C4, {dy_half, z_half, dz_half});
+    HP_LAUNCH_IOM(k_bn_bwd_apply_dual, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, relu_mask, z_a, z_b, z_half, dz_a, dz_b,
+                  dz_half, n4, C4, (const float4*)ca_a, (const float4*)cb_a, (const float4*)cc_a, (const float4*)ca_b,
+                  (const float4*)cb_b, (const float4*)cc_b);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

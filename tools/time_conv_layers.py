@@ -13,6 +13,8 @@ L = _lib.lib()
 T, N, B = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (128, 128, 4)))
 which = sys.argv[4] if len(sys.argv) > 4 else "fwd,dgrad,wgrad"
 ops.set_conv_precision(sys.argv[5] if len(sys.argv) > 5 else "fp32")
+ONLY = sys.argv[6].split(",") if len(sys.argv) > 6 else None   # layer-name prefixes
+HALF = ops.get_conv_precision() == "bf16s"   # bf16 tensors in HBM (stem excepted), bf16 packed weights where the kernels take them
 
 
 def layers():
@@ -50,26 +52,38 @@ def timeit(fn, reps=3):
 
 print(f"T={T} N={N} B={B} precision={ops.get_conv_precision()}")
 for name, cin, cout, k, s, p, tr, d in layers():
-    x = torch.randn(B, *d, cin, device="cuda")
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        continue
+    half = HALF and cin > 1
+    dt = torch.bfloat16 if half else torch.float32
+    x = torch.randn(B, *d, cin, device="cuda").to(dt)
     w = torch.randn((cin, cout, k, k, k) if tr else (cout, cin, k, k, k), device="cuda") * 0.05
     desc = ops._desc(x, cout, k, s, p, tr)
     do = ops._out_dims(desc)
-    y = torch.empty(B, *do, cout, device="cuda")
-    gy = torch.randn_like(y)
+    y = torch.empty(B, *do, cout, device="cuda", dtype=dt)
+    gy = torch.randn(B, *do, cout, device="cuda").to(dt)
     st = ops._stream(x)
-    wf, wd = ops._pack(desc, w, True, True)
+    whf, whd = ops._w_half(desc, half, cin), ops._w_half(desc, half, cout)
+    wf, _ = ops._pack(desc, w, True, False, half=whf)
+    _, wd = ops._pack(desc, w, False, True, half=whd)
+    io_f = (ops.HP_IO_X | ops.HP_IO_Y if half else 0) | (ops.HP_IO_W if whf else 0)
+    io_d = (ops.HP_IO_X | ops.HP_IO_DX | ops.HP_IO_DY if half else 0) | (ops.HP_IO_W if whd else 0)
+    io_w = ops.HP_IO_X | ops.HP_IO_DX | ops.HP_IO_DY if half else 0
     mout = B * do[0] * do[1] * do[2]
     flops = 2.0 * mout * (8 if tr else k ** 3) * cin * cout
     dx = torch.empty_like(x)
     dwp = torch.empty(int(L.hp_conv3d_packed_weight_elems(C.byref(desc))), device="cuda")
     res = []
     if "fwd" in which:
+        desc.io = io_f
         t = timeit(lambda: L.hp_conv3d_forward(C.byref(desc), x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), None, st))
         res.append(f"fwd {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
     if "dgrad" in which:
+        desc.io = io_d
         t = timeit(lambda: L.hp_conv3d_backward_data(C.byref(desc), gy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, st))
         res.append(f"dgrad {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
     if "wgrad" in which:
+        desc.io = io_w
         t = timeit(lambda: L.hp_conv3d_backward_weight(C.byref(desc), x.data_ptr(), gy.data_ptr(), dwp.data_ptr(), st))
         res.append(f"wgrad {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
     print(f"{name:14s} {cin:5d}->{cout:5d} k{k} s{s} in{d} GF {flops/1e9:8.1f} | " + " | ".join(res), flush=True)
