@@ -1006,38 +1006,65 @@ constexpr int SLD = 65;
 constexpr int SG_KW = 9;                                  // padded kw slots per cell
 constexpr int SG_N = 4 * SP_Y * SR_X * SG_KW;             // staging floats per wave
 
+template <bool HB>
 __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
-                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px) {
-  __shared__ float As[SP_M * SLD];
-  __shared__ float Bs[32 * SLD];
+                                                   float* __restrict__ dX, int D, int H, int W, int pz, int py, int px,
+                                                   int zchunk) {
+  // HB: the patch GEMM runs on the bf16 matrix cores (bf16 modes): both tiles are kept as bf16 rows of SHD = 72 elements
+  // (144 bytes: the 16-byte fragment reads of 16 rows fall on 16 distinct 16-byte slots), operands rounded on their way in,
+  // 4 v_mfma_f32_32x32x16_bf16 per chunk instead of 32 fp32 ones -- the fold, unchanged, then sets the pace.
+  constexpr int SHD = 72;
+  __shared__ __attribute__((aligned(16))) float As[HB ? SP_M * SHD / 2 : SP_M * SLD];
+  __shared__ __attribute__((aligned(16))) float Bs[HB ? 32 * SHD / 2 : 32 * SLD];
+  __bf16* const Ah = (__bf16*)As;
+  __bf16* const Bh = (__bf16*)Bs;
   __shared__ float stage[4 * SG_N];
   __shared__ float patch[SR_N];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // A workgroup walks a run of patches along z in its (y, x) column.  The output patch is a ring of 10 planes: moving
+  // on by one patch (4 planes) completes the 4 oldest planes -- only those are flushed to dX (fp32 atomics: the halo in
+  // y and x is shared with the neighbouring columns) and become the 4 newest, zeroed; the other 6 carry over.  The dZ
+  // tile of the next patch is fetched into registers while this one is multiplied and folded.
   int t = blockIdx.x;
   const int bx = t % px;
   t /= px;
   const int by = t % py;
-  const int bz = t / py;
-  (void)pz;
+  const int zs = t / py;
+  const int bz_beg = zs * zchunk, bz_end = min(pz, bz_beg + zchunk);
   const int b = blockIdx.y;
-  const int z0 = bz * SP_Z, y0 = by * SP_Y, x0 = bx * SP_X;
+  const int y0 = by * SP_Y, x0 = bx * SP_X;
   for (int i = tid; i < SR_N; i += CT) patch[i] = 0.f;
-  {  // A tile: 128 voxels x 64 channels
-    const int q = tid & 15, r0 = tid >> 4;
+  float4 areg[SP_M / 16];
+  const int aq = tid & 15, ar0 = tid >> 4;
+  auto fetch_a = [&](int bz) {  // A tile: 128 voxels x 64 channels
 #pragma unroll
     for (int pss = 0; pss < SP_M / 16; ++pss) {
-      const int r = r0 + 16 * pss;
+      const int r = ar0 + 16 * pss;
       const int rz = r / (SP_Y * SP_X), ry = (r / SP_X) % SP_Y, rx = r % SP_X;
-      const int z = z0 + rz, y = y0 + ry, x = x0 + rx;
-      float4 v = make_float4(0, 0, 0, 0);
-      if (z < D && y < H && x < W) v = *(const float4*)(dZ + ((((long)b * D + z) * H + y) * W + x) * 64 + q * 4);
-      float* d = As + r * SLD + q * 4;
-      d[0] = v.x;
-      d[1] = v.y;
-      d[2] = v.z;
-      d[3] = v.w;
+      const int z = bz * SP_Z + rz, y = y0 + ry, x = x0 + rx;
+      areg[pss] = (z < D && y < H && x < W) ? *(const float4*)(dZ + ((((long)b * D + z) * H + y) * W + x) * 64 + aq * 4)
+                                           : make_float4(0, 0, 0, 0);
     }
-  }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int pss = 0; pss < SP_M / 16; ++pss) {
+      const int r = ar0 + 16 * pss;
+      if constexpr (HB) {
+        *(bf16x4*)(Ah + r * SHD + aq * 4) = to_bf16x4(areg[pss]);
+      } else {
+        float* d = As + r * SLD + aq * 4;
+        d[0] = areg[pss].x;
+        d[1] = areg[pss].y;
+        d[2] = areg[pss].z;
+        d[3] = areg[pss].w;
+      }
+    }
+  };
+  if (bz_beg < bz_end) fetch_a(bz_beg);
+  int ring = 0;  // ring slot of the patch's first plane (z0 - 3)
+  const __bf16* const ahp = Ah + (wave * 32 + (lane & 31)) * SHD + 8 * (lane >> 5);
+  const __bf16* const bhp = Bh + (lane & 31) * SHD + 8 * (lane >> 5);
   const float* ap = As + (wave * 32 + (lane & 31)) * SLD + (lane >> 5);
   const float* bp = Bs + (lane & 31) * SLD + (lane >> 5);
   float* sw = stage + wave * SG_N;
@@ -1057,24 +1084,15 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
                                      : make_float4(0, 0, 0, 0);
     }
   };
-  fetch_w(0);
-  // Fold bookkeeping, fixed per lane: cell (cyr, cx) of pass p = lane + 64 p; bit (gi * 7 + kw) of fmask[p] says
-  // whether term (gi, kw) of the cell lies inside the 4 x 8 (jy, jx) slice parked by this wave.
-  int fbase[2], fcell[2];
-  unsigned fmask[2];
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int cell = lane + 64 * pass;
-    const int cyr = cell / SR_X, cx = cell - cyr * SR_X;
-    unsigned m = 0u;
-    for (int gi = 0; gi < 4; ++gi)
-      for (int kw = 0; kw < 7; ++kw)
-        if (cell < 7 * SR_X && (unsigned)(cyr - gi) < (unsigned)SP_Y && (unsigned)(cx - kw) < (unsigned)SP_X) m |= 1u << (gi * 7 + kw);
-    fmask[pass] = m;
-    // staging index of term (gi, kw): jy = cyr - gi  =>  fbase + gi * (3 * SR_X * SG_KW) + kw; lanes without a cell read slot 0
-    fbase[pass] = cell < 7 * SR_X ? (cyr * SR_X + cx) * SG_KW : 0;
-    fcell[pass] = cyr * SR_X + cx;
-  }
+  // Fold bookkeeping, fixed per lane: lane < 56 owns the staging position (jy, cx) of this wave's slice and sums, for each
+  // of the chunk's kh rows gi, the 7 kw slots parked there: sum_kw P[(jy, cx - kw)][(gi, kw)] -- the part of output cell
+  // (row jy + gi, cx) that comes from voxel row jy.  Slots (cx, kw) with cx - kw outside the 8-voxel run are never written
+  // by the park and stay zero from the start, so no term needs a validity test.  The four parts of a lane then go to four
+  // different patch rows, one kh row at a time (lanes of one step hit distinct cells; LDS operations of a wave are ordered).
+  const int f_jy = lane / SR_X, f_cx = lane - f_jy * SR_X;
+  const bool f_on = lane < SP_Y * SR_X;
+  const int fbase = f_on ? (f_jy * SR_X + f_cx) * SG_KW : 0;
+  for (int i = tid; i < 4 * SG_N; i += CT) stage[i] = 0.f;
   // Software pipeline over the 14 tap chunks: while the matrix cores run chunk c (a dependent chain of 32 MFMAs
   // on one accumulator tile), the same wave folds the P tile of chunk c-1 that it parked in its private staging
   // array -- two LDS reads per MFMA slot -- so the fold costs no time of its own.  Workgroup barriers are needed
@@ -1083,48 +1101,61 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
     constexpr bool MM = decltype(mm_c)::value, FOLD = decltype(fold_c)::value;
     const int pc = chunk - 1;  // the chunk being folded
     const int kdp = pc >> 1, kh0p = (pc & 1) * 4;
-    const unsigned gmask = (pc & 1) ? 0x1FFFFFu : 0xFFFFFFFu;  // odd chunks hold 3 kh rows
+    const int nkh_p = (pc & 1) ? 3 : 4;  // odd chunks hold 3 kh rows (the 4th staging row keeps the previous chunk's values)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float fsum[2] = {0.f, 0.f}, fpend[2] = {0.f, 0.f};
+    float fpart[4] = {0.f, 0.f, 0.f, 0.f};
     float fa = 0.f, fb = 0.f;
-    if constexpr (MM) {
+    bf16x8 ha[HB ? 4 : 1], hb[HB ? 4 : 1];
+    if constexpr (MM && HB) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        ha[ks] = *(const bf16x8*)(ahp + ks * 16);
+        hb[ks] = *(const bf16x8*)(bhp + ks * 16);
+      }
+    }
+    if constexpr (MM && !HB) {
       fa = ap[0];
       fb = bp[0];
     }
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
       float na = 0.f, nb = 0.f;
-      if constexpr (MM) {
+      if constexpr (MM && !HB) {
         if (kk + 1 < 32) {
           na = ap[2 * (kk + 1)];
           nb = bp[2 * (kk + 1)];
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
       }
+      if constexpr (MM && HB) {  // the 4 K steps of the chunk, spread over the fold slots
+        if ((kk & 7) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[kk >> 3], hb[kk >> 3], acc, 0, 0, 0);
+      }
       if constexpr (FOLD) {
-        // slot kk issues the two staging reads of term (gi, kw) = (kk / 7, kk % 7) and adds those of slot kk - 1:
-        // every read is unconditional (always inside this wave's staging array), the select drops foreign terms
-        if (kk >= 1 && kk < 29) {
-          const int bit = kk - 1;
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) fsum[pass] += ((fmask[pass] & gmask) >> bit & 1u) ? fpend[pass] : 0.f;
-        }
+        // slots 0 .. 27: term (gi, kw) = (kk / 7, kk % 7), one unconditional staging read and one add each;
+        // slots 28 .. 31: the part of kh row gi = kk - 28 goes to patch row kh0 + gi + jy of this wave's plane
         if (kk < 28) {
           const int gi = kk / 7, kw = kk % 7;  // compile-time after unrolling
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) fpend[pass] = sw[fbase[pass] + gi * (3 * SR_X * SG_KW) + kw];
-        } else if (kk >= 29 && kk < 31) {
-          const int pass = kk - 29;
-          if (lane + 64 * pass < 7 * SR_X) patch[((wave + kdp) * SR_Y + kh0p) * SR_X + fcell[pass]] += fsum[pass];
+          fpart[gi] += sw[fbase + gi * (SP_Y * SR_X * SG_KW) + kw];
+        } else {
+          const int gi = kk - 28;
+          int slot = ring + wave + kdp;  // plane (wave + kdp) of the patch
+          slot = slot >= SR_Z ? slot - SR_Z : slot;
+          if (f_on && gi < nkh_p) patch[(slot * SR_Y + kh0p + gi + f_jy) * SR_X + f_cx] += fpart[gi];
+          // the next kh row's update of ANOTHER lane reads the cell this lane just wrote: keep the four read-add-write
+          // steps in program order (per lane their addresses differ, so the compiler would otherwise be free to hoist
+          // the later reads above this write)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if constexpr (MM) {
+      if constexpr (MM && !HB) {
         fa = na;
         fb = nb;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // fp32: pin the fold slot to its MFMA; bf16: only 4 MFMAs per chunk -- the compiler is free to batch the fold's reads
+      if constexpr (!HB) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MM) {
       // park P: register r is voxel (jy = r>>2, jx = (r&3) + 4*half) of this wave's z slice
@@ -1135,6 +1166,12 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
       }
     }
   };
+  for (int bz = bz_beg; bz < bz_end; ++bz) {
+  const int z0 = bz * SP_Z;
+  __syncthreads();  // the previous patch's last fragment reads of the A tile are done
+  store_a();
+  if (bz + 1 < bz_end) fetch_a(bz + 1);
+  fetch_w(0);
   for (int chunk = 0; chunk <= 14; ++chunk) {
     __syncthreads();  // every wave is through the fragment reads of the previous weight tile and its patch update
     if (chunk < 14) {
@@ -1142,11 +1179,15 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
       for (int h = 0; h < 2; ++h) {
         const int i = tid + h * CT;
         const int tr = i >> 4, q = i & 15;
-        float* d = Bs + tr * SLD + q * 4;
-        d[0] = wv[h].x;
-        d[1] = wv[h].y;
-        d[2] = wv[h].z;
-        d[3] = wv[h].w;
+        if constexpr (HB) {
+          *(bf16x4*)(Bh + tr * SHD + q * 4) = to_bf16x4(wv[h]);
+        } else {
+          float* d = Bs + tr * SLD + q * 4;
+          d[0] = wv[h].x;
+          d[1] = wv[h].y;
+          d[2] = wv[h].z;
+          d[3] = wv[h].w;
+        }
       }
     }
     __syncthreads();
@@ -1157,11 +1198,19 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
     else step(std::false_type{}, std::true_type{}, chunk);
   }
   __syncthreads();
-  for (int i = tid; i < SR_N; i += CT) {
-    const int cz = i / (SR_Y * SR_X), cy = (i / SR_X) % SR_Y, cx = i % SR_X;
+  // planes z0 - 3 .. z0 are complete (the next patch starts at z0 + 1); the last patch of the run flushes all 10
+  const int nfl = (bz + 1 < bz_end ? SP_Z : SR_Z) * SR_Y * SR_X;
+  for (int i = tid; i < nfl; i += CT) {
+    const int cz = i / (SR_Y * SR_X), rem = i - cz * (SR_Y * SR_X), cy = rem / SR_X, cx = rem - cy * SR_X;
     const int z = z0 + cz - 3, y = y0 + cy - 3, x = x0 + cx - 3;
+    int slot = ring + cz;
+    slot = slot >= SR_Z ? slot - SR_Z : slot;
+    float* const cell = patch + slot * (SR_Y * SR_X) + rem;
     if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-      atomicAdd(dX + (((long)b * D + z) * H + y) * W + x, patch[i]);
+      atomicAdd(dX + (((long)b * D + z) * H + y) * W + x, *cell);
+    *cell = 0.f;
+  }
+  ring = ring + SP_Z >= SR_Z ? ring + SP_Z - SR_Z : ring + SP_Z;
   }
 }
 
@@ -1913,8 +1962,15 @@ extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void*
     else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     HP_PROF("conv_stem_dgrad", st);
-    hipLaunchKernelGGL(k_stem_dgrad, dim3((unsigned)(pz * py * px), (unsigned)d->B), dim3(CT), 0, st, (const float*)dy, w_dgrad, (float*)dx,
-                       d->Di, d->Hi, d->Wi, pz, py, px);
+    // single-plane bf16 arithmetic: the patch GEMM on the bf16 matrix cores (fp32 in, fp32 out either way)
+    // ~1024 workgroups (2 resident per CU), each walking zchunk patches along z
+    const long cols = (long)py * px * d->B;
+    int zsplit = (int)std::max<long>(1, std::min<long>(pz, (1024 + cols - 1) / cols));
+    if (const char* e = getenv("HP_STEM_DGRAD_ZSPLIT")) zsplit = std::max(1, std::min(pz, atoi(e)));  // tests: long runs on small volumes
+    const int zchunk = (pz + zsplit - 1) / zsplit;
+    zsplit = (pz + zchunk - 1) / zchunk;
+    hipLaunchKernelGGL(p.planes == 1 ? k_stem_dgrad<true> : k_stem_dgrad<false>, dim3((unsigned)(py * px * zsplit), (unsigned)d->B), dim3(CT), 0,
+                       st, (const float*)dy, w_dgrad, (float*)dx, d->Di, d->Hi, d->Wi, pz, py, px, zchunk);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }

@@ -95,6 +95,34 @@ def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims, precisio
     assert rel_l2(dw, wd.grad) < tol_g
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("zsplit", [1, 2])
+def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch):
+    """The stem's data gradient keeps its output patch as a ring of planes while a workgroup walks several 4-plane
+    patches along z (HP_STEM_DGRAD_ZSPLIT forces runs of 6 / 3 patches on this small volume; depth 22 ends in a partial
+    patch, H and W are not tile multiples).  fp32: the exact kernel; bf16: the patch GEMM on the bf16 matrix cores with
+    operands on the bf16 grid (exact products).  Also the stem weight gradient of the bf16 modes on the same case."""
+    monkeypatch.setenv("HP_STEM_DGRAD_ZSPLIT", str(zsplit))
+    g = torch.Generator().manual_seed(77)
+    B, D, H, W = 2, 22, 7, 11
+    x = torch.randn(B, 1, D, H, W, generator=g)
+    w = torch.randn(64, 1, 7, 7, 7, generator=g) / np.sqrt(343.0)
+    gy = torch.randn(B, 64, D, H, W, generator=g)
+    if precision == "bf16":
+        x, w, gy = _bf16_grid(x), _bf16_grid(w), _bf16_grid(gy)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (F.conv3d(xd, wd, padding=3) * gy.double()).sum().backward()
+    prev = ops.set_conv_precision(precision)
+    try:
+        xc = cl(x).cuda()
+        desc = ops._desc(xc, 64, 7, 1, 3, False)
+        dx, dw = ops._conv_grads(desc, xc, w.cuda(), cl(gy).cuda(), True)
+    finally:
+        ops.set_conv_precision(prev)
+    assert rel_l2(ncdhw(dx), xd.grad) < 5e-6
+    assert rel_l2(dw, wd.grad) < 5e-6
+
+
 @pytest.mark.parametrize("train,relu,with_res", [(True, True, True), (True, True, False), (False, True, True), (True, False, False)])
 def test_conv_bn_act_unit(train, relu, with_res):
     g = torch.Generator().manual_seed(11)
