@@ -177,7 +177,16 @@ struct TileCfg {
 // XH: the gathered tensor is bf16 in memory (NP = 1 only): K tiles of 64 channels, so that a thread still moves 16 bytes per
 // row and load (8 bf16) -- half the loads, K tiles and barriers per MAC of the fp32-storage path -- and the A tile goes to
 // LDS as loaded, without a conversion.
-template <int BN, bool STEM, bool STATS, int NP, bool XH = false>
+// 128 zero bytes: where a direct-to-LDS load (GL tiles) has to deliver zeros (padding taps, rows past M / Nout)
+__device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
+
+// GL (with XH, bf16 packed weights): both tiles go from memory straight into LDS (global_load_lds_dwordx4: no staging
+// registers, no ds_write pass), into two buffers of unpadded 128-byte rows, so that the loads of tile t+1 are in flight
+// while tile t is multiplied and one barrier per K tile suffices.  A wave-instruction of such a load writes 1 KB
+// linearly (lane l -> base + 16 l = 8 rows x 8 chunks), so the bank spread comes from the SOURCE side: LDS chunk c of row r
+// holds memory chunk c ^ ((r >> 1) & 7), and the fragment reads apply the same XOR (16 rows of a ds_read_b128 lane group
+// then fall on 16 distinct 16-byte slots).
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false>
 __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, void* __restrict__ Y,
                                               double* __restrict__ stats, const void* __restrict__ addend,
@@ -211,11 +220,14 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   constexpr bool BF = NP > 0;  // NP = 0: exact-fp32 MFMA; NP >= 1: bf16 MFMA on NP operand planes
   constexpr int NPL = NP > 0 ? NP : 1;
   static_assert(!XH || (NP == 1 && !STEM), "bf16-storage tiles: single bf16 plane, not the stem");
+  static_assert(!GL || (XH && BN >= 64), "direct-to-LDS tiles: bf16 storage, 64 or 128 columns");
   constexpr int BKT = XH ? 64 : BK;      // K extent of a tile
-  constexpr int LDX = BKT + 8;           // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
+  constexpr int LDX = GL ? BKT : BKT + 8;  // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
   constexpr int EPL = XH ? 8 : 4;        // elements per thread, row and load
   constexpr int ARENA0 = (BM + BN) * LDK > NP * (BM + BN) * LDH / 2 ? (BM + BN) * LDK : NP * (BM + BN) * LDH / 2;
-  constexpr int ARENA = XH && (BM + BN) * LDX / 2 > ARENA0 ? (BM + BN) * LDX / 2 : ARENA0;
+  constexpr int ARENA1 = XH && (BM + BN) * LDX / 2 > ARENA0 ? (BM + BN) * LDX / 2 : ARENA0;
+  constexpr int GLBUF = (BM + BN) * 64;  // bf16 elements per buffer (GL)
+  constexpr int ARENA = GL ? GLBUF : ARENA1;  // GL: two buffers of (BM + BN) x 64 bf16 = (BM + BN) * 64 floats
   __shared__ __attribute__((aligned(16))) float smem[ARENA];
   float* const As = smem;
   float* const Bs = smem + BM * LDK;
@@ -243,7 +255,9 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
 
   // ---- per-thread gather rows: r0 + 32 i
-  const int kq = tid & 7, r0 = tid >> 3;
+  const int kq0 = tid & 7, r0 = tid >> 3;
+  // GL: this thread's LDS chunk kq0 of rows r0 + 32 i is filled from memory chunk kq0 ^ swizzle(row) (same for every i)
+  const int kq = GL ? (kq0 ^ ((r0 >> 1) & 7)) : kq0;
   int rb[4], rz[4], ry[4], rx[4];
   bool rv[4];
 #pragma unroll
@@ -424,13 +438,69 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  if constexpr (GL) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned short* const xh16 = (const unsigned short*)Xv;
+    const unsigned short* const wh16 = (const unsigned short*)Wp;
+    // issue the loads of K tile (ld_tap, ld_ci) into buffer `buf`, then advance the running tile
+    auto stage = [&](int buf) {
+      __bf16* const ab = Ah + buf * GLBUF;
+      __bf16* const bb = ab + BM * 64;
+      const long xb = ld_xoff + ld_ci * BKT;
+      const long wbo = ld_woff + ld_ci * BKT;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const void* src = (vmask[i] & 1ull) ? (const void*)(xh16 + xb + rowoff[i]) : (const void*)g_zero_row;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ab + (i * 32 + wave * 8) * 64), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) {
+        const void* src = wvalid[i] ? (const void*)(wh16 + wbo + wrow[i]) : (const void*)g_zero_row;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bb + (i * 32 + wave * 8) * 64), 16, 0, 0);
+      }
+      if (++ld_ci == kpt) {
+        ld_ci = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vmask[i] >>= 1;
+        if (++ld_tap < ntaps) tap_offsets(ld_tap);
+      }
+    };
+    const int swz = ((lane & 31) >> 1) & 7, hf = lane >> 5;
+    int ck[4];  // element offset of this lane's 16 bytes of K step ks inside its (swizzled) row
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ck[ks] = (((2 * ks + hf) ^ swz) * 8);
+    const int arow = (wm * C::TM * 32 + (lane & 31)) * 64, brow = BM * 64 + (wn * C::TN * 32 + (lane & 31)) * 64;
+    stage(0);
+    for (int kt = 0; kt < KT; ++kt) {
+      // tile kt has landed (this wave's loads; the barrier covers the other waves') and every wave is through the reads of
+      // the buffer that tile kt + 1 is about to overwrite
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < KT) stage((kt + 1) & 1);
+      const __bf16* const tb = Ah + (kt & 1) * GLBUF;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 ha[C::TM], hb[C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) ha[i] = *(const bf16x8*)(tb + arow + i * 32 * 64 + ck[ks]);
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) hb[j] = *(const bf16x8*)(tb + brow + j * 32 * 64 + ck[ks]);
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
   const float* ap = As + (wm * C::TM * 32 + (lane & 31)) * LDK + (lane >> 5);
   const float* bp = Bs + (wn * C::TN * 32 + (lane & 31)) * LDK + (lane >> 5);
   constexpr int LDF = XH ? LDX : LDH;  // bf16 fragment row stride
   const __bf16* ahp = Ah + (wm * C::TM * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   const __bf16* bhp = Bh + (wn * C::TN * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   // kt = -1 is the prologue: one call site for the gather keeps the pipeline uniform
-  for (int kt = -1; kt < KT; ++kt) {
+  for (int kt = -1; kt < (GL ? -1 : KT); ++kt) {
     if (kt + 1 < KT) load_tile(kt + 1);
     if (BF && kt >= 0) {
       // v_mfma_f32_32x32x16_bf16: lane (row = lane&31, half = lane>>5) feeds k = 8*half .. 8*half+7
@@ -1783,13 +1853,28 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
     if (g.xh && g.Cin % 64 == 0) return launch_igemm_bn<STEM, STATS, NP, true>(g, classes, X, W, bias, Y, stats, addend, amask, st);
   }
   const unsigned mt = (unsigned)((g.M + BM - 1) / BM);
+  // bf16 packed weights as well: tiles loaded straight into LDS (HP_IGEMM_GL=0 keeps the register-staged tiles: A/B runs)
+  static const bool gl_on = !(getenv("HP_IGEMM_GL") && atoi(getenv("HP_IGEMM_GL")) == 0);
+  const bool gl = XH && g.wh && gl_on;
   if (g.Nout > 64) {
     const unsigned tn = (unsigned)((g.Nout + 127) / 128);
     IgemmGeom gg = g;
     gg.tn = tn > 1 ? (int)tn : 0;  // XCD-aware 1-D grid (see k_igemm)
     const dim3 grid = tn > 1 ? dim3((mt + 7) / 8 * 8 * tn, 1, classes) : dim3(mt, 1, classes);
+    if constexpr (XH) {
+      if (gl) {
+        hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP, true, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
+        return;
+      }
+    }
     hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP, XH>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
   } else if (g.Nout > 32) {
+    if constexpr (XH) {
+      if (gl) {
+        hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP, true, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
+        return;
+      }
+    }
     hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP, XH>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
   } else {
     hipLaunchKernelGGL((k_igemm<32, STEM, STATS, NP, XH>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
