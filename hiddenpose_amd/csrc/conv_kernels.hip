@@ -1540,6 +1540,168 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_bf16(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------- stem forward on the bf16 matrix cores
+// out[v][n] = sum_tap x[v + tap] w[n][tap] for the bf16 modes.  K = taps, ordered (kd, kh) pair by pair with the 7 kw taps of a
+// pair padded to 8 (zero weight): the 8 consecutive K elements a lane feeds to v_mfma_f32_32x32x16_bf16 are then 8
+// consecutive voxels of one input row -- two aligned ds_read_b64 of the four-times-shifted input patch of k_stem_wgrad_bf16 --
+// and a K step of 16 is two (kd, kh) pairs (25 steps for 49 pairs + 1 empty).  Rows of an MFMA tile = a 4 (y) x 8 (x) slice of
+// voxels, columns = 32 output channels; a wave owns two z slices x 64 channels.  Workgroup = 8 waves = a 16 x 4 x 8 voxel tile
+// (22 x 10 x 14 patch); the weights sit in LDS as [pair][channel][8] bf16 (50 KB) for the whole run of tiles of a persistent
+// workgroup, the next patch is fetched into registers during the multiply, BatchNorm statistics collect in registers and
+// leave in one fp64 atomic per channel and workgroup.  fp32 in, fp32 out, operands rounded to bf16 on their way into LDS.
+constexpr int SFH_TZ = 16, SFH_TY = 4, SFH_TX = 8, SFH_PZ = SFH_TZ + 6, SFH_PR = 28, SFH_PP = 10 * SFH_PR;
+constexpr int SFH_COPY = SFH_PZ * SFH_PP + 8;           // bf16 per shifted copy (+ 2 quad-words: bank shift between copies)
+constexpr int SFH_W = 50 * 64 * 8;                      // weight image, bf16
+constexpr int SFH_NP = SFH_PZ * 10 * 14;                // patch elements
+constexpr int SFH_LD = (SFH_NP + 511) / 512;            // patch elements per thread
+
+__global__ __launch_bounds__(512) void k_stem_fwd_bf16(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                       float* __restrict__ Y, double* __restrict__ stats, int D, int H, int W,
+                                                       int kpad, int pz, int py, int px, long tiles_total, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float sfh_smem[];
+  __bf16* const wl = (__bf16*)sfh_smem;
+  __bf16* const patch = wl + SFH_W;
+  float* const red = (float*)(patch + 4 * SFH_COPY);  // [8 waves][64 channels][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
+  for (int sidx = tid; sidx < 50 * 64; sidx += 512) {
+    const int pr = sidx >> 6, n = sidx & 63;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (pr < 49 && c < 7) ? Wp[(long)n * kpad + pr * 7 + c] : 0.f;
+    *(bf16x4*)(wl + sidx * 8) = to_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+    *(bf16x4*)(wl + sidx * 8 + 4) = to_bf16x4(make_float4(v[4], v[5], v[6], v[7]));
+  }
+  for (int i = tid; i < 4 * SFH_COPY / 2; i += 512) ((unsigned int*)patch)[i] = 0u;  // row pads stay zero for good
+  const long t0 = (long)blockIdx.x * tiles_per_wg, t1 = min(tiles_total, t0 + tiles_per_wg);
+  float preg[SFH_LD];
+  auto tile_origin = [&](long t, int& b, int& z0, int& y0, int& x0) {
+    long r_ = t;
+    x0 = (int)(r_ % px) * SFH_TX;
+    r_ /= px;
+    y0 = (int)(r_ % py) * SFH_TY;
+    r_ /= py;
+    z0 = (int)(r_ % pz) * SFH_TZ;
+    b = (int)(r_ / pz);
+  };
+  auto fetch = [&](long t) {
+    int b, z0, y0, x0;
+    tile_origin(t, b, z0, y0, x0);
+#pragma unroll
+    for (int k = 0; k < SFH_LD; ++k) {
+      const int e = tid + 512 * k;
+      const int pzz = e / 140, rem = e - pzz * 140, pyy = rem / 14, pxx = rem - pyy * 14;
+      const int z = z0 + pzz - 3, y = y0 + pyy - 3, x = x0 + pxx - 3;
+      preg[k] = (e < SFH_NP && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    ? X[(((long)b * D + z) * H + y) * W + x]
+                    : 0.f;
+    }
+  };
+  // A operand: lane (row = voxel (y = col >> 3, x = col & 7) of z slice 2 wave + mt, K half) starts at patch element
+  // abase[mt] + (kd * PP + kh * PR) of its half's (kd, kh) pair
+  int abase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) abase[mt] = (2 * wave + mt) * SFH_PP + (col >> 3) * SFH_PR + (col & 7);
+  float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+  if (t0 < t1) fetch(t0);
+  for (long t = t0; t < t1; ++t) {
+    __syncthreads();  // the previous tile's fragment reads are done (first trip: weights and zeroed patch are in place)
+#pragma unroll
+    for (int k = 0; k < SFH_LD; ++k) {
+      const int e = tid + 512 * k;
+      const int pzz = e / 140, rem = e - pzz * 140, pyy = rem / 14, pxx = rem - pyy * 14;
+      if (e < SFH_NP) {
+        const int pi = pzz * SFH_PP + pyy * SFH_PR + pxx;
+        const __bf16 v = (__bf16)preg[k];
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft)
+          if (pi - sft >= 0) patch[sft * SFH_COPY + pi - sft] = v;  // copy s holds element i + s at index i
+      }
+    }
+    __syncthreads();
+    int b, z0, y0, x0;
+    tile_origin(t, b, z0, y0, x0);
+    if (t + 1 < t1) fetch(t + 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    int kd = 0, kh = half;  // pair 2 ks + half
+#pragma unroll 5
+    for (int ks = 0; ks < 25; ++ks) {
+      const int pr = 2 * ks + half;
+      const int off = pr < 49 ? kd * SFH_PP + kh * SFH_PR : 0;
+      bf16x8 ha[2], hb[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int e = abase[mt] + off;
+        const __bf16* const src = patch + (e & 3) * SFH_COPY + (e & ~3);
+        union {
+          uint2 q[2];
+          bf16x8 f;
+        } u;
+        u.q[0] = *(const uint2*)(src);
+        u.q[1] = *(const uint2*)(src + 4);
+        ha[mt] = u.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) hb[nt] = *(const bf16x8*)(wl + ((pr * 64) + nt * 32 + col) * 8);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[mt], hb[nt], acc[mt][nt], 0, 0, 0);
+      kh += 2;
+      if (kh >= 7) {
+        kh -= 7;
+        ++kd;
+      }
+    }
+    // epilogue: register r of a tile is voxel row (r & 3) + 8 (r >> 2) + 4 half, column = channel nt * 32 + col
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int z = z0 + 2 * wave + mt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int y = y0 + (i >> 3), x = x0 + (i & 7);
+        if (z < D && y < H && x < W) {
+          float* const yo = Y + ((((long)b * D + z) * H + y) * W + x) * 64 + col;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float v = acc[mt][nt][r];
+            yo[nt * 32] = v;
+            ssum[nt] += v;
+            ssq[nt] += v * v;
+          }
+        }
+      }
+    }
+  }
+  if (stats) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float sv = ssum[nt] + __shfl_xor(ssum[nt], 32), qv = ssq[nt] + __shfl_xor(ssq[nt], 32);
+      if (half == 0) {
+        red[(wave * 64 + nt * 32 + col) * 2 + 0] = sv;
+        red[(wave * 64 + nt * 32 + col) * 2 + 1] = qv;
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double sv = 0.0, qv = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        sv += (double)red[(w * 64 + tid) * 2 + 0];
+        qv += (double)red[(w * 64 + tid) * 2 + 1];
+      }
+      atomicAdd(stats + tid, sv);
+      atomicAdd(stats + 64 + tid, qv);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- stem forward on the 4x4x1 matrix-core instruction
 // The stem (1 -> 64 channels, 7^3 taps) as a GEMM has K = 343 taps of a single-channel volume: the generic kernel
 // gathers its A tile element by element.  With v_mfma_f32_4x4x1_16b_f32 (16 blocks of a 4x4 outer product; row i =
@@ -1976,7 +2138,22 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const void* x, const flo
              "hp_conv3d_forward: bf16 packed weights go with a bf16 input, HP_PRECISION_BF16 and Cin %% 64 == 0");
   hipStream_t st = (hipStream_t)stream;
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
-  if (p.stem && p.planes == 0 && d->Cout == 64 && !bias && !p.fwd.yh) {
+  if (p.stem && p.planes == 1 && d->Cout == 64 && !bias && !p.fwd.yh) {
+    // single-plane bf16 arithmetic: persistent workgroups (one per CU: 100 KB of LDS), 16 x 4 x 8 voxel tiles
+    const int pz = (d->Di + SFH_TZ - 1) / SFH_TZ, py = (d->Hi + SFH_TY - 1) / SFH_TY, px = (d->Wi + SFH_TX - 1) / SFH_TX;
+    const long tiles = (long)d->B * pz * py * px;
+    const int per_wg = (int)std::max<long>(1, (tiles + 511) / 512);
+    const size_t lds = sizeof(__bf16) * (SFH_W + 4 * SFH_COPY) + sizeof(float) * 8 * 64 * 2;
+    static std::once_flag lds_once_h;
+    static hipError_t lds_rc_h = hipSuccess;
+    std::call_once(lds_once_h, [&] {
+      lds_rc_h = hipFuncSetAttribute((const void*)k_stem_fwd_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    HP_CHECK_HIP(lds_rc_h);
+    HP_PROF("conv_igemm_stem", st);
+    hipLaunchKernelGGL(k_stem_fwd_bf16, dim3((unsigned)((tiles + per_wg - 1) / per_wg)), dim3(512), lds, st, (const float*)x, w_fwd,
+                       (float*)y, stats, d->Di, d->Hi, d->Wi, p.fwd.kpt * BK, pz, py, px, tiles, per_wg);
+  } else if (p.stem && p.planes == 0 && d->Cout == 64 && !bias && !p.fwd.yh) {
     // dedicated 4x4x1-MFMA stem kernel: ~1024 workgroups, one resident per CU (138 KB of LDS)
     const int tiles_x = (d->Wi + SF_TX - 1) / SF_TX, tiles_y = (d->Hi + SF_TY - 1) / SF_TY;
     const long cols = (long)tiles_x * tiles_y * d->B;
