@@ -347,16 +347,18 @@ def bench_highres(args):
                                       "peak_tflops": MFMA_F32_PEAK_TFLOPS}}), flush=True)
 
 
-def quick_native(args, local, note):
-    """The same train step at the reference's native shape (128x128x128, batch 4), 1 warm-up + 3 timed steps."""
+def quick_native(args, local, note, workload="native", precision=None, label="reference-native shape"):
+    """The same train step at another shape / arithmetic (default: the reference's native 128x128x128, batch 4),
+    1 warm-up + 3 timed steps."""
     from hiddenpose_amd import testing as hpt
     from hiddenpose_amd.config import make_cfg
     from hiddenpose_amd.NlosPose import NlosPose
     from hiddenpose_amd.train_epoch import build_training, train_step
 
-    T, N, B = WORKLOADS["native"]
+    T, N, B = WORKLOADS[workload]
+    precision = precision or args.conv_precision
     dev = torch.device("cuda", local)
-    cfg = make_cfg(T, N, device=local, conv_precision=args.conv_precision)
+    cfg = make_cfg(T, N, device=local, conv_precision=precision)
     model = NlosPose(cfg).to(dev).train()
     criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
     meas = hpt.synthetic_meas(B, T, N, "transient", seed=410).to(dev)
@@ -370,8 +372,8 @@ def quick_native(args, local, note):
         train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, None)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    note(f"extra: native 128^3 batch {B}: {1e3 * dt / steps:.1f} ms/step")
-    return {"workload": f"NlosPose train step, {N}x{N}x{T} (reference-native shape), batch {B}, {args.conv_precision}",
+    note(f"extra: {N}x{N}x{T} batch {B} {precision}: {1e3 * dt / steps:.1f} ms/step")
+    return {"workload": f"NlosPose train step, {N}x{N}x{T} ({label}), batch {B}, {precision}",
             "ms_per_step": round(1e3 * dt / steps, 3), "value": round(B * steps / dt, 3), "unit": "samples/s", "steps": steps,
             "warmup": 1}
 
@@ -587,6 +589,11 @@ def main():
             model = optimizer = criterion = voxel_criterion = meas = vol = joints = None
             torch.cuda.empty_cache()
             line["extra"] = {"native_128": quick_native(args, local, note)}
+            if args.conv_precision == "fp32":
+                # BASELINE configs[2]'s per-GPU share (bf16 arithmetic + bf16 activation storage, fp32 LCT) on the headline cube
+                torch.cuda.empty_cache()
+                line["extra"]["configs2_bf16s"] = quick_native(args, local, note, "t512", "bf16s",
+                                                              "headline cube, configs[2] arithmetic and storage")
         if world == 1 and not args.no_cpu_baseline:
             # the box's CPU share for one GPU is 16 cores: more threads than that only oversubscribe
             try:

@@ -16,6 +16,10 @@ f=$(find $O/stats -name 't512_kernel_stats.csv' | head -1); cp "$f" profiles/${R
 tail -1 $O/t512_bench.json > profiles/${R}_t512_bench_under_rocprof.json
 python3 tools/aggregate_pmc.py $(find $O/fetch -name 'f_counter_collection.csv' | head -1) $(find $O/write -name 'w_counter_collection.csv' | head -1) 4 \
     profiles/${R}_t512_pmc_hbm_traffic.csv profiles/t512_pmc_hbm_traffic.json > $O/agg_t512.txt || exit 5
+# BASELINE configs[2]'s per-GPU share: the same step with bf16 arithmetic and bf16 activation storage
+rocprofv3 --kernel-trace --stats -d $O/bstats -o b16 --output-format csv -- python3 bench.py $A --conv-precision bf16s > $O/bf16s_bench.json 2> $O/bf16s_bench.err || exit 10
+f=$(find $O/bstats -name 'b16_kernel_stats.csv' | head -1); cp "$f" profiles/${R}_t512_bf16s_rocprofv3_kernel_stats.csv
+tail -1 $O/bf16s_bench.json > profiles/${R}_t512_bf16s_bench_under_rocprof.json
 H="--workload highres --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --stats -d $O/hstats -o hr --output-format csv -- python3 bench.py $H > $O/highres_bench.json 2> $O/highres_bench.err || exit 6
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/hfetch -o f --output-format csv -- python3 bench.py --workload highres --steps 2 --warmup 1 > /dev/null 2> $O/hfetch.err || exit 7
@@ -25,6 +29,6 @@ tail -1 $O/highres_bench.json > profiles/${R}_highres_bench_under_rocprof.json
 python3 tools/aggregate_pmc.py $(find $O/hfetch -name 'f_counter_collection.csv' | head -1) $(find $O/hwrite -name 'w_counter_collection.csv' | head -1) 3 \
     profiles/${R}_highres_pmc_hbm_traffic.csv > $O/agg_highres.txt || exit 9
 # the raw traces are scratch; keep the summaries
-rm -rf $O/stats $O/fetch $O/write $O/hstats $O/hfetch $O/hwrite
+rm -rf $O/stats $O/fetch $O/write $O/hstats $O/hfetch $O/hwrite $O/bstats
 mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* profiles/t512_pmc_hbm_traffic.json gpurun_out/profiles_$R/
 echo "profiles collected"; ls -la profiles | tail -12
