@@ -576,6 +576,58 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         for (int j = 0; j < C::TN; ++j) smem[rl * LDO + wn * C::TN * 32 + j * 32 + (lane & 31)] = acc[h][j][r];
       }
       __syncthreads();
+      if constexpr (IOH) {
+        // bf16 output (and addend): 8 channels = 16 bytes per lane (the memory-bound 1^3 layers spend their time here)
+        if (g.yh && (g.Nout & 7) == 0 && (!addend || g.ah)) {
+          constexpr int Q8 = BN / 8;
+#pragma unroll
+          for (int k2 = 0; k2 < (64 * Q8) / CT; ++k2) {
+            const int idx = tid + k2 * CT;
+            const int row64 = idx / Q8, q8 = idx - row64 * Q8;
+            const int trow = (row64 >> 5) * (C::TM * 32) + h * 32 + (row64 & 31);
+            const long m = m0 + trow;
+            const int n = n0 + 8 * q8;
+            if (m >= g.M || n >= g.Nout) continue;
+            long orow = m;
+            if (!dense_out) {
+              int b, z, y, x;
+              grid_coords(g, m, b, z, y, x);
+              orow = (long)(unsigned)(((b * g.Do + z * g.os + pd) * g.Ho + y * g.os + ph) * g.Wo + x * g.os + pw);
+            }
+            float4 v0 = *(const float4*)(smem + row64 * LDO + 8 * q8), v1 = *(const float4*)(smem + row64 * LDO + 8 * q8 + 4);
+            const long yo = orow * g.Nout + n;
+            if (bias) {
+              const float4 b0 = *(const float4*)(bias + n), b1 = *(const float4*)(bias + n + 4);
+              v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+              v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+            }
+            if (addend) {
+              const uint4 u = *(const uint4*)((const unsigned short*)addend + yo);
+              float4 a0 = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                      __uint_as_float(u.y & 0xffff0000u));
+              float4 a1 = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                                      __uint_as_float(u.w & 0xffff0000u));
+              if (amask) {
+                const unsigned mk = *(const unsigned short*)(amask + (yo >> 2));
+                a0.x = (mk & 1u) ? a0.x : 0.f; a0.y = (mk & 2u) ? a0.y : 0.f; a0.z = (mk & 4u) ? a0.z : 0.f; a0.w = (mk & 8u) ? a0.w : 0.f;
+                a1.x = (mk & 0x100u) ? a1.x : 0.f; a1.y = (mk & 0x200u) ? a1.y : 0.f; a1.z = (mk & 0x400u) ? a1.z : 0.f;
+                a1.w = (mk & 0x800u) ? a1.w : 0.f;
+              }
+              v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w;
+              v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+            }
+            const bf16x4 l = to_bf16x4(v0), hgh = to_bf16x4(v1);
+            union {
+              bf16x4 h4[2];
+              uint4 u;
+            } o;
+            o.h4[0] = l;
+            o.h4[1] = hgh;
+            *(uint4*)((unsigned short*)Y + yo) = o.u;
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int k2 = 0; k2 < (64 * Q) / CT; ++k2) {
         const int idx = tid + k2 * CT;
