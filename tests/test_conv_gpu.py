@@ -433,6 +433,54 @@ def test_conv_bf16_storage(name, cin, cout, k, s, p, tr, dims):
         assert rel_l2(ncdhw(dx2.float()), xd.grad + add.double()) < 4e-3
 
 
+@pytest.mark.parametrize("stride,downsample", [(1, False), (2, True)], ids=["identity", "downsample_s2"])
+def test_bottleneck_bf16_storage(stride, downsample):
+    """A whole Bottleneck with bf16 activation storage (64 / 256 channels: every convolution takes the direct-to-LDS
+    tiles, the identity shortcut the 16-byte masked-addend epilogue, the stride-2 block the parity-class data gradient)
+    against the same block in float64.  Each of the ~10 tensors between input and output is rounded to bf16 once
+    (2^-9) and the ReLU masks move with it, so the bars are a few per cent -- an indexing slip anywhere in the tile
+    loads, the swizzle or the epilogue shows as an O(1) error."""
+    import copy
+
+    from hiddenpose_amd.posenet3d_50 import Bottleneck
+
+    g = torch.Generator().manual_seed(31 + stride)
+    planes = 64
+    cin = 128 if downsample else planes * 4
+    ds = None
+    if downsample:
+        ds = torch.nn.Sequential(torch.nn.Conv3d(cin, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm3d(planes * 4))
+    blk = Bottleneck(cin, planes, stride, ds)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_(_bf16_grid(torch.randn(prm.shape, generator=g) * (0.08 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 else 0.0)))
+    B, D = 2, 8
+    x = _bf16_grid(torch.randn(B, cin, D, D, D, generator=g))
+    ref = copy.deepcopy(blk).double().train(True)
+    xr = x.double().requires_grad_(True)
+    pre = torch.relu(xr * 1.0)
+    o = torch.relu(ref.bn1(ref.conv1(pre)))
+    o = torch.relu(ref.bn2(ref.conv2(o)))
+    o = ref.bn3(ref.conv3(o))
+    yr = torch.relu(o + (ref.downsample(pre) if ref.downsample is not None else pre))
+    gy = _bf16_grid(torch.randn(yr.shape, generator=g))
+    (yr * gy.double()).sum().backward()
+
+    blk = blk.cuda().train(True)
+    prev = ops.set_conv_precision("bf16s")
+    try:
+        xg = cl(x).cuda().requires_grad_(True)
+        y = blk(torch.relu(xg * 1.0).to(torch.bfloat16))
+        assert y.dtype == torch.bfloat16
+        (y.float() * cl(gy).cuda()).sum().backward()
+    finally:
+        ops.set_conv_precision(prev)
+    assert rel_l2(ncdhw(y.float()), yr) < 2e-2
+    assert rel_l2(ncdhw(xg.grad), xr.grad) < 8e-2
+    for (n, pg), (_, pr) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert rel_l2(pg.grad, pr.grad) < 0.15, n   # measured <= 0.08 (BatchNorm biases: sums over flipped ReLU masks)
+
+
 @pytest.mark.parametrize("with_res", [True, False])
 def test_conv_bn_act_unit_bf16_storage(with_res):
     """One conv + BatchNorm + ReLU (+ residual) unit with bf16 activation storage against the same unit in the bf16
