@@ -376,7 +376,13 @@ def test_weight_gradients_on_side_stream_match_serial():
         assert rel_l2(got[k], ref[k]) < 1e-4, k
 
 
-BF16S_CASES = [c for c in CASES if c[0] != "stem"]
+BF16S_CASES = [c for c in CASES if c[0] != "stem"] + [
+    # power-of-two grids with rows a multiple of a weight-gradient step (32 voxels): the wave-uniform row addressing of the
+    # bf16-storage weight gradient, with taps that leave the row on both sides, a strided and a transposed case
+    ("k3_runx", 64, 64, 3, 1, 1, False, (2, 4, 8, 32)),
+    ("k3_s2_runx", 64, 128, 3, 2, 1, False, (1, 4, 8, 64)),
+    ("deconv_runx", 64, 64, 4, 2, 1, True, (1, 2, 4, 32)),
+]
 
 
 @pytest.mark.parametrize("name,cin,cout,k,s,p,tr,dims", BF16S_CASES, ids=[c[0] for c in BF16S_CASES])
