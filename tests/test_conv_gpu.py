@@ -101,7 +101,8 @@ def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch
     """The stem's data gradient keeps its output patch as a ring of planes while a workgroup walks several 4-plane
     patches along z (HP_STEM_DGRAD_ZSPLIT forces runs of 6 / 3 patches on this small volume; depth 22 ends in a partial
     patch, H and W are not tile multiples).  fp32: the exact kernel; bf16: the patch GEMM on the bf16 matrix cores with
-    operands on the bf16 grid (exact products).  Also the stem weight gradient of the bf16 modes on the same case."""
+    operands on the bf16 grid (exact products).  Also the stem forward (with its BatchNorm statistics) and the stem weight
+    gradient of either mode on the same case."""
     monkeypatch.setenv("HP_STEM_DGRAD_ZSPLIT", str(zsplit))
     g = torch.Generator().manual_seed(77)
     B, D, H, W = 2, 22, 7, 11
@@ -111,14 +112,27 @@ def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch
     if precision == "bf16":
         x, w, gy = _bf16_grid(x), _bf16_grid(w), _bf16_grid(gy)
     xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
-    (F.conv3d(xd, wd, padding=3) * gy.double()).sum().backward()
+    ref = F.conv3d(xd, wd, padding=3)
+    (ref * gy.double()).sum().backward()
     prev = ops.set_conv_precision(precision)
     try:
+        import ctypes as C
+
+        from hiddenpose_amd import _lib
         xc = cl(x).cuda()
         desc = ops._desc(xc, 64, 7, 1, 3, False)
+        # forward at the same odd extents (depth 22: the 16-plane tiles of the bf16-mode stem kernel end in a partial tile)
+        wf, _ = ops._pack(desc, w.cuda(), True, False)
+        y = torch.empty(B, D, H, W, 64, device="cuda")
+        stats = torch.empty(128, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().hp_conv3d_forward(C.byref(desc), xc.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(),
+                                                ops._stream(xc)), "fwd")
         dx, dw = ops._conv_grads(desc, xc, w.cuda(), cl(gy).cuda(), True)
     finally:
         ops.set_conv_precision(prev)
+    assert rel_l2(ncdhw(y), ref) < 2e-6
+    refcl = cl(ref.detach())
+    assert rel_l2(stats[:64], refcl.reshape(-1, 64).sum(0)) < 2e-5 and rel_l2(stats[64:], (refcl.reshape(-1, 64) ** 2).sum(0)) < 2e-5
     assert rel_l2(ncdhw(dx), xd.grad) < 5e-6
     assert rel_l2(dw, wd.grad) < 5e-6
 
