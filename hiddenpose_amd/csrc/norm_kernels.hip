@@ -5,6 +5,7 @@
 // one fp64 atomic per channel per block.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <initializer_list>
 
 #include "hp_internal.h"
@@ -12,6 +13,9 @@
 namespace hp {
 
 constexpr int ET = 256;
+#ifndef HP_BN_UNR_H
+#define HP_BN_UNR_H 8
+#endif
 
 // Element-type plumbing of the BatchNorm passes.  IOM = 0: every tensor fp32, IOM = 1: every tensor bf16 -- both known
 // at compile time, so a pass issues all its loads back to back (a run-time type test per access put a conversion, and
@@ -111,29 +115,41 @@ __global__ __launch_bounds__(ET) void k_bn_apply(const void* __restrict__ z, int
   constexpr int Q = IO::Q;
   const long ng = n4 / Q;
   const int CG = C4 / Q;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
-    const int c0 = (int)(i % CG) * Q;
-    float4 v[Q], q[Q], o[Q];
-    IO::ld(z, i, z_half, v);
-    if (res) IO::ld(res, i, res_half, q);
-    unsigned mk = 0u;
+  // The grid stride is usually a multiple of the channel groups per row: a thread then meets the same channels in every
+  // trip and keeps their affine maps in registers (the per-trip parameter loads -- 4 to 8 per tensor load -- had the pass
+  // bound by vector-memory instructions rather than by bytes, most of all with two channel quads per lane).
+  const long stride = (long)gridDim.x * ET;
+  const bool fixed = stride % CG == 0;
+  float4 scv[Q], shv[Q], sc2v[Q], sh2v[Q];
+  auto params = [&](int c0) {
 #pragma unroll
     for (int e = 0; e < Q; ++e) {
       const int c = c0 + e;
       const float4 m = mean[c], r = rstd[c], g = gamma[c], b = beta[c];
       // y = z * sc + sh with sc = rstd * gamma, sh = beta - mean * sc: the backward rebuilds the ReLU mask with
       // exactly this expression
-      const float4 sc = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
-      const float4 sh = make_float4(b.x - m.x * sc.x, b.y - m.y * sc.y, b.z - m.z * sc.z, b.w - m.w * sc.w);
-      o[e] = f4_fma(v[e], sc, sh);
+      scv[e] = make_float4(r.x * g.x, r.y * g.y, r.z * g.z, r.w * g.w);
+      shv[e] = make_float4(b.x - m.x * scv[e].x, b.y - m.y * scv[e].y, b.z - m.z * scv[e].z, b.w - m.w * scv[e].w);
+      if (rmean) {  // the residual is a raw convolution output with a BatchNorm of its own still to be applied
+        const float4 m2 = rmean[c], r2 = rrstd[c], g2 = rgamma[c], b2 = rbeta[c];
+        sc2v[e] = make_float4(r2.x * g2.x, r2.y * g2.y, r2.z * g2.z, r2.w * g2.w);
+        sh2v[e] = make_float4(b2.x - m2.x * sc2v[e].x, b2.y - m2.y * sc2v[e].y, b2.z - m2.z * sc2v[e].z, b2.w - m2.w * sc2v[e].w);
+      }
+    }
+  };
+  if (fixed) params((int)(((long)blockIdx.x * ET + threadIdx.x) % CG) * Q);
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += stride) {
+    if (!fixed) params((int)(i % CG) * Q);
+    float4 v[Q], q[Q], o[Q];
+    IO::ld(z, i, z_half, v);
+    if (res) IO::ld(res, i, res_half, q);
+    unsigned mk = 0u;
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      o[e] = f4_fma(v[e], scv[e], shv[e]);
       if (res) {
         float4 qq = q[e];
-        if (rmean) {  // the residual is a raw convolution output with a BatchNorm of its own still to be applied
-          const float4 m2 = rmean[c], r2 = rrstd[c], g2 = rgamma[c], b2 = rbeta[c];
-          const float4 sc2 = make_float4(r2.x * g2.x, r2.y * g2.y, r2.z * g2.z, r2.w * g2.w);
-          const float4 sh2 = make_float4(b2.x - m2.x * sc2.x, b2.y - m2.y * sc2.y, b2.z - m2.z * sc2.z, b2.w - m2.w * sc2.w);
-          qq = f4_fma(qq, sc2, sh2);
-        }
+        if (rmean) qq = f4_fma(qq, sc2v[e], sh2v[e]);
         o[e].x += qq.x;
         o[e].y += qq.y;
         o[e].z += qq.z;
@@ -301,13 +317,21 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply(const void* __restrict__ g,
   constexpr int Q = IO::Q;
   const long ng = n4 / Q;
   const int CG = C4 / Q;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
-    const int c0 = (int)(i % CG) * Q;
+  const long stride = (long)gridDim.x * ET;
+  const bool fixed = stride % CG == 0;  // see k_bn_apply
+  float4 av[Q], bv[Q], kv[Q];
+  auto params = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < Q; ++e) av[e] = ca[c0 + e], bv[e] = cb[c0 + e], kv[e] = cc[c0 + e];
+  };
+  if (fixed) params((int)(((long)blockIdx.x * ET + threadIdx.x) % CG) * Q);
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += stride) {
+    if (!fixed) params((int)(i % CG) * Q);
     float4 gg[Q], v[Q], o[Q];
     IO::ld(g, i, g_half, gg);
     IO::ld(z, i, z_half, v);
 #pragma unroll
-    for (int e = 0; e < Q; ++e) o[e] = f4_dz(gg[e], v[e], ca[c0 + e], cb[c0 + e], cc[c0 + e]);
+    for (int e = 0; e < Q; ++e) o[e] = f4_dz(gg[e], v[e], av[e], bv[e], kv[e]);
     IO::st(dz, i, o, dz_half);
   }
 }
@@ -325,21 +349,31 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_mask(const void* __restrict
   constexpr int Q = IO::Q;
   const long ng = n4 / Q;
   const int CG = C4 / Q;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
-    const int c0 = (int)(i % CG) * Q;
+  const long stride = (long)gridDim.x * ET;
+  const bool fixed = stride % CG == 0;  // see k_bn_apply
+  float4 av[Q], bv[Q], kv[Q], scv[Q], shv[Q];
+  auto params = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      const int c = c0 + e;
+      av[e] = ca[c], bv[e] = cb[c], kv[e] = cc[c];
+      if (relu) {
+        const float4 m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
+        scv[e] = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
+        shv[e] = make_float4(be.x - m.x * scv[e].x, be.y - m.y * scv[e].y, be.z - m.z * scv[e].z, be.w - m.w * scv[e].w);
+      }
+    }
+  };
+  if (fixed) params((int)(((long)blockIdx.x * ET + threadIdx.x) % CG) * Q);
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += stride) {
+    if (!fixed) params((int)(i % CG) * Q);
     float4 gg[Q], v[Q], o[Q];
     IO::ld(dy, i, dy_half, gg);
     IO::ld(z, i, z_half, v);
 #pragma unroll
     for (int e = 0; e < Q; ++e) {
-      const int c = c0 + e;
-      if (relu) {
-        const float4 m = mean[c], r = rstd[c], ga = gamma[c], be = beta[c];
-        const float4 sc = make_float4(r.x * ga.x, r.y * ga.y, r.z * ga.z, r.w * ga.w);
-        const float4 sh = make_float4(be.x - m.x * sc.x, be.y - m.y * sc.y, be.z - m.z * sc.z, be.w - m.w * sc.w);
-        gg[e] = f4_gate(gg[e], f4_fma(v[e], sc, sh));
-      }
-      o[e] = f4_dz(gg[e], v[e], ca[c], cb[c], cc[c]);
+      if (relu) gg[e] = f4_gate(gg[e], f4_fma(v[e], scv[e], shv[e]));
+      o[e] = f4_dz(gg[e], v[e], av[e], bv[e], kv[e]);
     }
     IO::st(dz, i, o, dz_half);
   }
@@ -358,14 +392,22 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_bytemask(const void* __rest
   constexpr int Q = IO::Q;
   const long ng = n4 / Q;
   const int CG = C4 / Q;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
-    const int c0 = (int)(i % CG) * Q;
+  const long stride = (long)gridDim.x * ET;
+  const bool fixed = stride % CG == 0;  // see k_bn_apply
+  float4 av[Q], bv[Q], kv[Q];
+  auto params = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < Q; ++e) av[e] = ca[c0 + e], bv[e] = cb[c0 + e], kv[e] = cc[c0 + e];
+  };
+  if (fixed) params((int)(((long)blockIdx.x * ET + threadIdx.x) % CG) * Q);
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += stride) {
+    if (!fixed) params((int)(i % CG) * Q);
     float4 gg[Q], v[Q], o[Q];
     IO::ld(dy, i, dy_half, gg);
     const unsigned mk = IO::ldm(mask, i);
     IO::ld(z, i, z_half, v);
 #pragma unroll
-    for (int e = 0; e < Q; ++e) o[e] = f4_dz(f4_mask(gg[e], mk >> (8 * e)), v[e], ca[c0 + e], cb[c0 + e], cc[c0 + e]);
+    for (int e = 0; e < Q; ++e) o[e] = f4_dz(f4_mask(gg[e], mk >> (8 * e)), v[e], av[e], bv[e], kv[e]);
     IO::st(dz, i, o, dz_half);
   }
 }
@@ -476,8 +518,19 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_dual(const void* __restrict
   constexpr int Q = IO::Q;
   const long ng = n4 / Q;
   const int CG = C4 / Q;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += (long)gridDim.x * ET) {
-    const int c0 = (int)(i % CG) * Q;
+  const long stride = (long)gridDim.x * ET;
+  const bool fixed = stride % CG == 0;  // see k_bn_apply
+  float4 aa[Q], ba[Q], ka[Q], ab[Q], bb[Q], kb[Q];
+  auto params = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < Q; ++e) {
+      aa[e] = caa[c0 + e], ba[e] = cba[c0 + e], ka[e] = cca[c0 + e];
+      ab[e] = cab[c0 + e], bb[e] = cbb[c0 + e], kb[e] = ccb[c0 + e];
+    }
+  };
+  if (fixed) params((int)(((long)blockIdx.x * ET + threadIdx.x) % CG) * Q);
+  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < ng; i += stride) {
+    if (!fixed) params((int)(i % CG) * Q);
     float4 gg[Q], va[Q], vb[Q], oa[Q], ob[Q];
     IO::ld(dy, i, dy_half, gg);
     const unsigned mk = IO::ldm(mask, i);
@@ -486,8 +539,8 @@ __global__ __launch_bounds__(ET) void k_bn_bwd_apply_dual(const void* __restrict
 #pragma unroll
     for (int e = 0; e < Q; ++e) {
       const float4 g = f4_mask(gg[e], mk >> (8 * e));
-      oa[e] = f4_dz(g, va[e], caa[c0 + e], cba[c0 + e], cca[c0 + e]);
-      ob[e] = f4_dz(g, vb[e], cab[c0 + e], cbb[c0 + e], ccb[c0 + e]);
+      oa[e] = f4_dz(g, va[e], aa[e], ba[e], ka[e]);
+      ob[e] = f4_dz(g, vb[e], ab[e], bb[e], kb[e]);
     }
     IO::st(dza, i, oa, dz_half);
     IO::st(dzb, i, ob, dz_half);
@@ -1020,13 +1073,17 @@ extern "C" int hp_bn_backward(const void* dy, const float* y, const void* z, voi
                       : gbuf ? io_mode(C4, {dy_half, z_half, dz_half}) : io_mode(C4, {dy_half, z_half});
     const int CG = C4 / (iom == 1 ? 2 : 1);
     const int rows_per_pass = CG < ET ? ET / CG : 1;
-    const unsigned nb = (unsigned)std::min<long>((M + rows_per_pass - 1) / rows_per_pass, 256 * 2);
+    // at most two workgroups per CU, and at least HP_BN_RED_TRIPS (default 16) trips of 4 rows per thread: a workgroup's fixed
+    // cost (parameter loads, the cross-row reduction, 2C fp64 atomics) is paid per workgroup, and on the small tensors of the
+    // deep layers a grid sized by rows alone spends most of its time there
+    static const int trips_min = getenv("HP_BN_RED_TRIPS") ? atoi(getenv("HP_BN_RED_TRIPS")) : 16;
+    const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(M / ((long)rows_per_pass * 4 * trips_min), 256 * 2));
     if (iom == 0)
       hipLaunchKernelGGL((k_bn_bwd_reduce<4, 0>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
                          C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma, (const float4*)beta_for_mask,
                          relu_mask);
     else if (iom == 1)
-      hipLaunchKernelGGL((k_bn_bwd_reduce<4, 1>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
+      hipLaunchKernelGGL((k_bn_bwd_reduce<HP_BN_UNR_H, 1>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
                          C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma, (const float4*)beta_for_mask,
                          relu_mask);
     else
