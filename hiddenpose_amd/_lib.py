@@ -73,7 +73,11 @@ SIGNATURES = {
     "hp_maxpool3d_k2_forward": (_i, [_fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_maxpool3d_k2_backward": (_i, [_fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_upsample_trilinear2x_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_upsample_trilinear2x_forward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "hp_upsample_trilinear2x_forward_ws": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_upsample_trilinear2x_backward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "hp_upsample_trilinear2x_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "hp_upsample_trilinear2x_backward_ws": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_channel_slice_copy": (_i, [_fp, _fp, _i, _i, C.c_long, _i, _i, _i, _vp]),
     "hp_conv1x1_forward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
     "hp_conv1x1_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),

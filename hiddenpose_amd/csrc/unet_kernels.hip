@@ -421,6 +421,130 @@ __global__ __launch_bounds__(UT) void k_upsample2_bwd(const float* __restrict__ 
   }
 }
 
+// ---- separable adjoint: trilinear interpolation is a product of three 1-D maps, so its adjoint is three 1-D passes
+// (w, h, d), each summing the <= 5 outputs of ONE axis that read an input position:
+//     dst[plane][r][p][in] = sum_k wt[p][k] * src[plane'][r][lo[p] + k][in],   p < n (the axis shrinks 2n -> n)
+// 5 loads per element and pass instead of up to 125 in the fused gather; the traffic of the three passes together is
+// 2.6x the gradient tensor (1 + 1/2, 1/2 + 1/4, 1/4 + 1/8).  VEC = 4: four consecutive `in` per thread (h and d passes).
+// The first pass reads the channel slice [c_off, c_off + C) of the (B, Ctot, ...) gradient: plane' = b * Ctot + c_off + c.
+template <int VEC>
+__global__ __launch_bounds__(UT) void k_ups_adj_axis(const float* __restrict__ src, float* __restrict__ dst, unsigned total,
+                                                     int n, unsigned R, unsigned inner, int C, int Ctot, int c_off, int s_in,
+                                                     int s_n, int s_r) {
+  __shared__ int t_lo[1024], t_cnt[1024];
+  __shared__ float t_wt[1024 * 5];
+  for (int pos = threadIdx.x; pos < n; pos += UT) {
+    int lo;
+    const int m = adj_range(pos, n, lo);
+    int first = -1, cnt = 0;
+    float wts[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < m; ++a) {
+      int i0, i1;
+      float f;
+      lerp_src(lo + a, n, i0, i1, f);
+      const float wgt = (i0 == pos ? 1.f - f : 0.f) + (i1 == pos ? f : 0.f);
+      if (wgt != 0.f) {
+        if (first < 0) first = lo + a;
+        const int k = lo + a - first;
+        if (k < 5) {
+          wts[k] = wgt;
+          cnt = k + 1;
+        }
+      }
+    }
+    t_lo[pos] = first < 0 ? 0 : first;
+    t_cnt[pos] = cnt;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t_wt[pos * 5 + k] = wts[k];
+  }
+  __syncthreads();
+  const unsigned innerv = inner / VEC;
+  for (unsigned i = blockIdx.x * UT + threadIdx.x; i < total; i += gridDim.x * UT) {
+    unsigned in, p, r, pl;
+    if (s_in >= 0) {  // power-of-two extents
+      in = i & (innerv - 1);
+      p = (i >> s_in) & (unsigned)(n - 1);
+      r = (i >> (s_in + s_n)) & (R - 1);
+      pl = i >> (s_in + s_n + s_r);
+    } else {
+      in = i % innerv;
+      unsigned t = i / innerv;
+      p = t % (unsigned)n;
+      t /= (unsigned)n;
+      r = t % R;
+      pl = t / R;
+    }
+    const unsigned spl = Ctot > 0 ? (pl / (unsigned)C) * (unsigned)Ctot + (unsigned)c_off + pl % (unsigned)C : pl;
+    const int lo = t_lo[p], cnt = t_cnt[p];
+    const float* sp = src + (((long)spl * R + r) * (2 * n) + lo) * (long)inner + (long)in * VEC;
+    const int last = 2 * n - 1 - lo;  // clamp: rows beyond the axis are read (weight 0) at its last position
+    if constexpr (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = *(const float4*)(sp + (long)min(k, last) * inner);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float wk = k < cnt ? t_wt[p * 5 + k] : 0.f;
+        acc.x += wk * v[k].x;
+        acc.y += wk * v[k].y;
+        acc.z += wk * v[k].z;
+        acc.w += wk * v[k].w;
+      }
+      *(float4*)(dst + (((long)pl * R + r) * n + p) * (long)inner + (long)in * 4) = acc;
+    } else {
+      float acc = 0.f, v[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = sp[(long)min(k, last) * inner];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc += (k < cnt ? t_wt[p * 5 + k] : 0.f) * v[k];
+      dst[(((long)pl * R + r) * n + p) * (long)inner + in] = acc;
+    }
+  }
+}
+
+// ---- separable forward, in the reference's own order of interpolation (w, then h, then d: the same expression tree as
+// the fused kernel): dst[plane'][r][o][in] = src[..][i0(o)][in] * (1 - f(o)) + src[..][i1(o)][in] * f(o), o < 2n.
+// Two loads per element and pass instead of eight; the last pass (d) writes the channel slice of the concat buffer with
+// 16-byte stores.
+template <int VEC>
+__global__ __launch_bounds__(UT) void k_ups_interp_axis(const float* __restrict__ src, float* __restrict__ dst, unsigned total,
+                                                        int n, unsigned R, unsigned inner, int C, int Ctot, int c_off, int s_in,
+                                                        int s_n, int s_r) {
+  __shared__ int f_i0[2048], f_i1[2048];
+  __shared__ float f_w[2048];
+  for (int o = threadIdx.x; o < 2 * n; o += UT) lerp_src(o, n, f_i0[o], f_i1[o], f_w[o]);
+  __syncthreads();
+  const unsigned innerv = inner / VEC;
+  for (unsigned i = blockIdx.x * UT + threadIdx.x; i < total; i += gridDim.x * UT) {
+    unsigned in, o, r, pl;
+    if (s_in >= 0) {
+      in = i & (innerv - 1);
+      o = (i >> s_in) & (unsigned)(2 * n - 1);
+      r = (i >> (s_in + s_n)) & (R - 1);
+      pl = i >> (s_in + s_n + s_r);
+    } else {
+      in = i % innerv;
+      unsigned t = i / innerv;
+      o = t % (unsigned)(2 * n);
+      t /= (unsigned)(2 * n);
+      r = t % R;
+      pl = t / R;
+    }
+    const unsigned dpl = Ctot > 0 ? (pl / (unsigned)C) * (unsigned)Ctot + (unsigned)c_off + pl % (unsigned)C : pl;
+    const int i0 = f_i0[o], i1 = f_i1[o];
+    const float f = f_w[o];
+    const float* sp = src + ((long)pl * R + r) * n * (long)inner + (long)in * VEC;
+    float* dp = dst + (((long)dpl * R + r) * (2 * n) + o) * (long)inner + (long)in * VEC;
+    if constexpr (VEC == 4) {
+      const float4 a = *(const float4*)(sp + (long)i0 * inner), b = *(const float4*)(sp + (long)i1 * inner);
+      *(float4*)dp = make_float4(a.x * (1.f - f) + b.x * f, a.y * (1.f - f) + b.y * f, a.z * (1.f - f) + b.z * f, a.w * (1.f - f) + b.w * f);
+    } else {
+      *dp = sp[(long)i0 * inner] * (1.f - f) + sp[(long)i1 * inner] * f;
+    }
+  }
+}
+
 // copy (B, C, V) into channel slice [c_off, c_off+C) of (B, Ctot, V), or back (gather = 1)
 __global__ __launch_bounds__(UT) void k_channel_slice_copy(const float* __restrict__ src, float* __restrict__ dst, int B,
                                                            int C, long V, int Ctot, int c_off, int gather) {
@@ -630,6 +754,81 @@ extern "C" int hp_upsample_trilinear2x_backward(const float* dy, float* dx, int 
   pow2_shifts(D, H, W, sd, sh, sw);
   hipLaunchKernelGGL(k_upsample2_bwd, dim3(ugrid((long)B * C * D * H * W)), dim3(UT), 0, st, dy, dx, B, C, D, H, W, Ctot, c_off, sw, sh,
                      sd);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// workspace of the separable forward: x after the w pass (B,C,D,H,2W) and after the h pass (B,C,D,2H,2W)
+extern "C" size_t hp_upsample_trilinear2x_forward_workspace_bytes(int B, int C, int D, int H, int W) {
+  return sizeof(float) * ((size_t)B * C * D * H * 2 * W + (size_t)B * C * D * 2 * H * 2 * W);
+}
+
+extern "C" int hp_upsample_trilinear2x_forward_ws(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot, int c_off,
+                                                  void* workspace, void* stream) {
+  HP_REQUIRE(x && y && workspace && c_off >= 0 && c_off + C <= Ctot, "hp_upsample_trilinear2x_forward_ws: bad argument");
+  const size_t n1 = (size_t)B * C * D * H * 2 * W, n2 = (size_t)B * C * D * 2 * H * 2 * W, n3 = (size_t)B * C * 2 * D * 2 * H * 2 * W;
+  if (n3 >= (1ull << 32) || D > 1024 || H > 1024 || W > 1024 || W % 2 != 0)
+    return hp_upsample_trilinear2x_forward(x, y, B, C, D, H, W, Ctot, c_off, stream);
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("upsample2_fwd", st);
+  float* t1 = (float*)workspace;
+  float* t2 = t1 + n1;
+  auto lg = [](unsigned v) {
+    int l = 0;
+    while ((1u << l) < v) ++l;
+    return (1u << l) == v ? l : -1;
+  };
+  auto launch = [&](int vec, const float* src, float* dst, size_t total, int n, unsigned R, unsigned inner, int ctot) {
+    const unsigned innerv = inner / (unsigned)vec;
+    int s_in = lg(innerv), s_n = lg((unsigned)(2 * n)), s_r = lg(R);
+    if (s_in < 0 || s_n < 0 || s_r < 0) s_in = s_n = s_r = -1;
+    const unsigned tot = (unsigned)(total / (size_t)vec);
+    if (vec == 4)
+      hipLaunchKernelGGL(k_ups_interp_axis<4>, dim3(ugrid(tot)), dim3(UT), 0, st, src, dst, tot, n, R, inner, C, ctot, c_off, s_in, s_n, s_r);
+    else
+      hipLaunchKernelGGL(k_ups_interp_axis<1>, dim3(ugrid(tot)), dim3(UT), 0, st, src, dst, tot, n, R, inner, C, ctot, c_off, s_in, s_n, s_r);
+  };
+  launch(1, x, t1, n1, W, (unsigned)(D * H), 1u, 0);                         // w: (.., D*H rows, W)   -> (.., 2W)
+  launch(4, t1, t2, n2, H, (unsigned)D, (unsigned)(2 * W), 0);               // h: (.., D, H, 2W)      -> (.., 2H, 2W)
+  launch(4, t2, y, n3, D, 1u, (unsigned)(4 * H * W), Ctot);                  // d: (.., D, 2H*2W)      -> slice of (B, Ctot, 2D, 2H*2W)
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+// workspace of the separable backward: the gradient after the w pass (B,C,2D,2H,W) and after the h pass (B,C,2D,H,W)
+extern "C" size_t hp_upsample_trilinear2x_backward_workspace_bytes(int B, int C, int D, int H, int W) {
+  return sizeof(float) * ((size_t)B * C * 2 * D * 2 * H * W + (size_t)B * C * 2 * D * H * W);
+}
+
+extern "C" int hp_upsample_trilinear2x_backward_ws(const float* dy, float* dx, int B, int C, int D, int H, int W, int Ctot,
+                                                   int c_off, void* workspace, void* stream) {
+  HP_REQUIRE(dy && dx && workspace && c_off >= 0 && c_off + C <= Ctot, "hp_upsample_trilinear2x_backward_ws: bad argument");
+  const size_t n1 = (size_t)B * C * 2 * D * 2 * H * W, n2 = (size_t)B * C * 2 * D * H * W, n3 = (size_t)B * C * D * H * W;
+  // 32-bit element indices inside a pass, tables of 1024 positions per axis, float4 along w in the h and d passes
+  if (n1 >= (1ull << 32) || D > 1024 || H > 1024 || W > 1024 || W % 4 != 0)
+    return hp_upsample_trilinear2x_backward(dy, dx, B, C, D, H, W, Ctot, c_off, stream);
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("upsample2_bwd", st);
+  float* t1 = (float*)workspace;
+  float* t2 = t1 + n1;
+  auto lg = [](unsigned v) {
+    int l = 0;
+    while ((1u << l) < v) ++l;
+    return (1u << l) == v ? l : -1;
+  };
+  auto launch = [&](int vec, const float* src, float* dst, size_t total, int n, unsigned R, unsigned inner, int ctot) {
+    const unsigned innerv = inner / (unsigned)vec;
+    int s_in = lg(innerv), s_n = lg((unsigned)n), s_r = lg(R);
+    if (s_in < 0 || s_n < 0 || s_r < 0) s_in = s_n = s_r = -1;
+    const unsigned tot = (unsigned)(total / (size_t)vec);
+    if (vec == 4)
+      hipLaunchKernelGGL(k_ups_adj_axis<4>, dim3(ugrid(tot)), dim3(UT), 0, st, src, dst, tot, n, R, inner, C, ctot, c_off, s_in, s_n, s_r);
+    else
+      hipLaunchKernelGGL(k_ups_adj_axis<1>, dim3(ugrid(tot)), dim3(UT), 0, st, src, dst, tot, n, R, inner, C, ctot, c_off, s_in, s_n, s_r);
+  };
+  launch(1, dy, t1, n1, W, (unsigned)(2 * D * 2 * H), 1u, Ctot);              // w: (.., 2D*2H rows, 2W) -> (.., W)
+  launch(4, t1, t2, n2, H, (unsigned)(2 * D), (unsigned)W, 0);                 // h: (.., 2D, 2H, W)      -> (.., H, W)
+  launch(4, t2, dx, n3, D, 1u, (unsigned)(H * W), 0);                          // d: (.., 2D, H*W)        -> (.., D, H*W)
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

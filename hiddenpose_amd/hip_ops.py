@@ -322,8 +322,10 @@ class _UpsampleCat(torch.autograd.Function):
         with torch.cuda.device(x1.device):
             _lib.check(L.hp_channel_slice_copy(skip.data_ptr(), out.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 0, st),
                        "hp_channel_slice_copy")
-            _lib.check(L.hp_upsample_trilinear2x_forward(x1.data_ptr(), out.data_ptr(), b, c1, d, h, w, c1 + c2, c2, st),
-                       "hp_upsample_trilinear2x_forward")
+            ws = torch.empty(int(L.hp_upsample_trilinear2x_forward_workspace_bytes(b, c1, d, h, w)) // 4, dtype=torch.float32,
+                             device=x1.device)
+            _lib.check(L.hp_upsample_trilinear2x_forward_ws(x1.data_ptr(), out.data_ptr(), b, c1, d, h, w, c1 + c2, c2,
+                                                            ws.data_ptr(), st), "hp_upsample_trilinear2x_forward_ws")
         ctx.dims = (b, c1, c2, d, h, w)
         return out
 
@@ -338,8 +340,10 @@ class _UpsampleCat(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             _lib.check(L.hp_channel_slice_copy(dy.data_ptr(), dskip.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 1, st),
                        "hp_channel_slice_copy")
-            _lib.check(L.hp_upsample_trilinear2x_backward(dy.data_ptr(), dx1.data_ptr(), b, c1, d, h, w, c1 + c2, c2, st),
-                       "hp_upsample_trilinear2x_backward")
+            ws = torch.empty(int(L.hp_upsample_trilinear2x_backward_workspace_bytes(b, c1, d, h, w)) // 4, dtype=torch.float32,
+                             device=dy.device)
+            _lib.check(L.hp_upsample_trilinear2x_backward_ws(dy.data_ptr(), dx1.data_ptr(), b, c1, d, h, w, c1 + c2, c2,
+                                                             ws.data_ptr(), st), "hp_upsample_trilinear2x_backward_ws")
         return dx1, dskip
 
 

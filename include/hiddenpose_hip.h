@@ -271,8 +271,18 @@ int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* dx, long pl
  * read from channel slice [c_off, c_off+C) of a (B, Ctot, 2D, 2H, 2W) tensor: the torch.cat of :61 */
 int hp_upsample_trilinear2x_forward(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot, int c_off,
                                     void* stream);
+/* The same interpolation as three 1-D passes in the reference's order (w, h, d: identical arithmetic) through a
+ * caller-provided workspace: two loads per element and pass, 16-byte stores into the concat slice. */
+size_t hp_upsample_trilinear2x_forward_workspace_bytes(int B, int C, int D, int H, int W);
+int hp_upsample_trilinear2x_forward_ws(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot, int c_off,
+                                       void* workspace, void* stream);
 int hp_upsample_trilinear2x_backward(const float* dy, float* dx, int B, int C, int D, int H, int W, int Ctot, int c_off,
                                      void* stream);
+/* The same adjoint as three 1-D passes (w, h, d) through a caller-provided workspace: 5 loads per element and pass instead
+ * of up to 125 in the fused gather (falls back to it for extents the passes do not cover). */
+size_t hp_upsample_trilinear2x_backward_workspace_bytes(int B, int C, int D, int H, int W);
+int hp_upsample_trilinear2x_backward_ws(const float* dy, float* dx, int B, int C, int D, int H, int W, int Ctot, int c_off,
+                                        void* workspace, void* stream);
 /* (B,C,V) -> channel slice of (B,Ctot,V) (gather = 0) or the reverse (gather = 1) */
 int hp_channel_slice_copy(const float* src, float* dst, int B, int C, long V, int Ctot, int c_off, int gather,
                           void* stream);

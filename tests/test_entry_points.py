@@ -143,9 +143,12 @@ def test_prefetching_loader_matches_the_plain_loader(tmp_path):
     ids1 = [i for b in sh for i in b[3]]
     sh.set_epoch(0)
     assert [i for b in sh for i in b[3]] == ids0 and sorted(ids0) == sorted(ids1) and len(ids0) == 5
-    # a corrupt measurement file: sample 0 stands in
-    bad = ds.measFiles.index(str(base / "meas" / "p3.hdr"))
-    open(ds.measFiles[bad], "wb").write(b"not a radiance file")
+    # a corrupt measurement file: sample 0 stands in.  (The dataset lists files in directory order, as the reference does:
+    # the file to corrupt is picked by POSITION, any but the first -- corrupting "sample 0" itself leaves nothing to stand in.)
+    bad = 3
+    with open(ds.measFiles[bad], "wb") as f:
+        f.write(b"not a radiance file")
+    first = os.path.splitext(os.path.basename(ds.measFiles[0]))[0]
     fb = {i: (m, v) for b in PrefetchingLoader(ds, 1, drop_last=False, workers=2) for i, m, v in zip(b[3], b[0], b[1])}
-    ref0 = ds[ds.measFiles.index(str(base / "meas" / "p0.hdr"))]
-    assert len(ds.wrongMeasFiles) >= 1 and torch.equal(fb["p0"][0], ref0[0].cuda())
+    ref0 = ds[0]
+    assert len(ds.wrongMeasFiles) >= 1 and torch.equal(fb[first][0], ref0[0].cuda())
