@@ -17,7 +17,7 @@ FAMILY = [("k_wgrad", "conv_wgrad"), ("k_stem_wgrad", "conv_wgrad"), ("k_stem_fw
           ("k_bn_", "batchnorm"), ("k_stem_bwd", "stem_bn_pool"), ("k_bn_relu_pool3", "stem_bn_pool"), ("k_dconv3_wgrad", "dconv3_wgrad"), ("k_dconv3", "dconv3_fwd+dgrad"),
           ("k_stencil_c1", "dconv3_fwd+dgrad"), ("k_fold_replicate", "dconv3_fwd+dgrad"),
           ("k_maxpool3", "maxpool3"), ("k_axis_", "lct"), ("k_gn_", "groupnorm"), ("k_plane_stats", "groupnorm"), ("k_affine_relu", "groupnorm"),
-          ("k_upsample", "upsample"), ("at::native", "aten(autograd adds, Adam)")]
+          ("k_upsample", "upsample"), ("k_ups_", "upsample"), ("at::native", "aten(autograd adds, Adam)")]
 
 
 def family(name):
