@@ -50,7 +50,9 @@ def test_maxpool2_first_max_semantics():
     assert rel_l2(xg.grad, xd.grad) < 1e-7
 
 
-@pytest.mark.parametrize("dims", [(4, 4, 4), (1, 2, 3), (8, 2, 16)])
+# (4,4,4), (8,2,16): the separable passes with shift decodes; (3,6,12): their general (division) decode; (2,5,6): separable
+# forward, fused adjoint (W % 4 != 0); (1,2,3): both fused (odd W)
+@pytest.mark.parametrize("dims", [(4, 4, 4), (1, 2, 3), (8, 2, 16), (3, 6, 12), (2, 5, 6)])
 def test_upsample_cat(dims):
     g = gen(2)
     x1 = torch.randn(2, 3, *dims, generator=g)
