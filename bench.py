@@ -122,11 +122,13 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(threads: int):
+def cpu_baseline(threads: int, full: bool = False):
     """BASELINE.md section 3 protocol: the oracle (CPU restatement of the reference) on ONE 128x128x128 cube
     (= 1/4 of a 128x128x512 sample, `scaled_from`), 1 warm-up + 3 timed iterations, median; legs: forward only
-    (eval, no_grad) and the full train step (forward + losses + backward + Adam).  `value` is the train-step leg scaled
-    to 128x128x512 samples/s, i.e. the same unit as the GPU line."""
+    (eval, no_grad), the full train step (forward + losses + backward + Adam) and the LCT alone on one 512x128x128 volume.
+    `value` is the train-step leg scaled to 128x128x512 samples/s, i.e. the same unit as the GPU line.  The default run
+    is a bounded sample (about a minute of CPU work); `full` (--cpu-baseline-full) adds the remaining legs of the
+    protocol: batch 4 at 128^3 (forward, train step) and the LCT at 1024x256x256."""
     import statistics
 
     from hiddenpose_amd import testing as hpt
@@ -163,7 +165,44 @@ def cpu_baseline(threads: int):
     t_fwd = statistics.median(fwd() for _ in range(3))
     train()
     t_train = statistics.median(train() for _ in range(3))
-    return {"value": round(0.25 / t_train, 6), "unit": "samples/s", "cores": threads, "kind": "port",
+
+    def lct_leg(T_, N_):
+        kk = O.LCTConstants(N_, T_, 5.12 / T_)
+        x = hpt.synthetic_meas(1, T_, N_)
+
+        def run():
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.lct_forward(x, kk)
+            return time.perf_counter() - t0
+
+        run()
+        return statistics.median(run() for _ in range(3))
+
+    extra = {"lct_forward_s_512x128x128": round(lct_leg(512, 128), 3)}
+    if full:
+        B4 = 4
+        meas4, vol4 = hpt.synthetic_meas(B4, T, N), hpt.synthetic_vol(B4, T, N)
+        joints4 = hpt.synthetic_joints(B4, T // 2).reshape(B4, -1)
+
+        def run4(grad):
+            t0 = time.perf_counter()
+            if grad:
+                loss, *_ = O.train_loss(meas4, vol4, joints4, sd, k)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            else:
+                with torch.no_grad():
+                    O.train_loss(meas4, vol4, joints4, sd, k)
+            return time.perf_counter() - t0
+
+        run4(False)
+        extra["forward_s_batch4_128"] = round(statistics.median(run4(False) for _ in range(3)), 3)
+        run4(True)
+        extra["train_step_s_batch4_128"] = round(statistics.median(run4(True) for _ in range(3)), 3)
+        extra["lct_forward_s_1024x256x256"] = round(lct_leg(1024, 256), 3)
+    return {"value": round(0.25 / t_train, 6), "unit": "samples/s", "cores": threads, "kind": "port", **extra,
             "cpu_model": cpu_model_string(), "protocol": "1 warm-up + 3 timed, median",
             "scaled_from": "one 128x128x128 cube = 1/4 of a 128x128x512 sample (times x4)",
             "train_step_s_per_cube": round(t_train, 3), "forward_s_per_cube": round(t_fwd, 3),
@@ -400,6 +439,8 @@ def main():
     ap.add_argument("--dp-wire", default=os.environ.get("HP_DP_WIRE", "auto"), choices=["auto", "fp32", "bf16"],
                     help="dtype on the wire for the gradient exchange; auto = bf16 in the bf16 convolution modes "
                          "(BASELINE configs[2]), fp32 otherwise")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="all legs of BASELINE.md section 3 in cpu_baseline (adds batch 4 at 128^3 and the LCT at 1024x256x256: minutes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short 128^3 (reference-native shape) run reported under `extra`")
     args = ap.parse_args()
 
@@ -602,7 +643,7 @@ def main():
                 avail = os.cpu_count() or 1
             threads = max(1, min(16, avail))
             note(f"cpu_baseline: oracle train step on one 128^3 cube with {threads} threads ...")
-            line["cpu_baseline"] = cpu_baseline(threads)
+            line["cpu_baseline"] = cpu_baseline(threads, full=args.cpu_baseline_full)
             note("cpu_baseline done")
         print(json.dumps(line), flush=True)
     if world > 1:
