@@ -41,5 +41,9 @@ class NlosPose(nn.Module):
         n = meas.shape[0]
         window = ([self.time_begin] * n, [self.time_end] * n)
         feature = K.normalize_feature(self.feature_propagation(self.feature_extraction(meas), *window))
-        refine_feature = self.autoencoder(feature)
-        return self.pose_net(K.add(feature, refine_feature)), refine_feature
+        if isinstance(self.autoencoder, UNet3d) and self.autoencoder.in_channels == 1:
+            refine_feature, summed = self.autoencoder.forward_and_sum(feature)   # `feature + refine` in the same pass
+        else:
+            refine_feature = self.autoencoder(feature)
+            summed = K.add(feature, refine_feature)
+        return self.pose_net(summed), refine_feature

@@ -81,6 +81,8 @@ SIGNATURES = {
     "hp_channel_slice_copy": (_i, [_fp, _fp, _i, _i, C.c_long, _i, _i, _i, _vp]),
     "hp_conv1x1_forward": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
     "hp_conv1x1_backward": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
+    "hp_conv1x1_forward_sum": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
+    "hp_conv1x1_backward_sum": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, C.c_long, _vp]),
     "hp_leaky_add_forward": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _vp]),
     "hp_leaky_backward": (_i, [_fp, _fp, _fp, C.c_long, C.c_float, _vp]),
     "hp_normalize_feature_forward": (_i, [_fp, _fp, _i, C.c_long, C.c_float, _vp, _vp]),

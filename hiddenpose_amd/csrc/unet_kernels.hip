@@ -561,9 +561,11 @@ __global__ __launch_bounds__(UT) void k_channel_slice_copy(const float* __restri
 }
 
 // ---- 1x1x1 convolution with few channels (UNet `Out`: 4 -> 1)
+// addend / sum_out (optional, shaped like y): sum_out = y + addend in the same pass (NlosPose.py:57: the regressor's input
+// `feature + refine` leaves with the refined volume instead of through a launch of its own)
 __global__ __launch_bounds__(UT) void k_conv1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ y, int B, int cin,
-                                                  int cout, long V) {
+                                                  int cout, long V, const float* __restrict__ addend, float* __restrict__ sum_out) {
   const long total = (long)B * V;
   for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
     const long b = i / V, v = i - b * V;
@@ -571,6 +573,7 @@ __global__ __launch_bounds__(UT) void k_conv1_fwd(const float* __restrict__ x, c
       float s = bias ? bias[co] : 0.f;
       for (int ci = 0; ci < cin; ++ci) s = fmaf(x[(b * cin + ci) * V + v], w[co * cin + ci], s);
       y[(b * cout + co) * V + v] = s;
+      if (sum_out) sum_out[(b * cout + co) * V + v] = addend[(b * cout + co) * V + v] + s;
     }
   }
 }
@@ -578,8 +581,10 @@ __global__ __launch_bounds__(UT) void k_conv1_fwd(const float* __restrict__ x, c
 template <int CIN, int COUT>
 __global__ __launch_bounds__(UT) void k_conv1_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                   const float* __restrict__ dy, float* __restrict__ dx,
-                                                  float* __restrict__ dw, float* __restrict__ db, int B, long V) {
-  // per-thread partial sums, block reduction, one atomic per block and entry
+                                                  float* __restrict__ dw, float* __restrict__ db, int B, long V,
+                                                  const float* __restrict__ dy2) {
+  // per-thread partial sums, block reduction, one atomic per block and entry (dy2, optional: a second gradient of the
+  // same output, added on load -- the gradient that arrives through `feature + refine`)
   __shared__ float sh[2 * UT / 64];
   const long total = (long)B * V;
   float pw[CIN * COUT], pb[COUT], wr[CIN * COUT];
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(UT) void k_conv1_bwd(const float* __restrict__ x, c
     float g[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-      g[co] = dy[(b * COUT + co) * V + v];
+      g[co] = dy[(b * COUT + co) * V + v] + (dy2 ? dy2[(b * COUT + co) * V + v] : 0.f);
       pb[co] += g[co];
     }
 #pragma unroll
@@ -846,16 +851,27 @@ extern "C" int hp_channel_slice_copy(const float* src, float* dst, int B, int C,
 
 extern "C" int hp_conv1x1_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout,
                                   long V, void* stream) {
+  return hp_conv1x1_forward_sum(x, w, bias, nullptr, y, nullptr, B, cin, cout, V, stream);
+}
+
+extern "C" int hp_conv1x1_forward_sum(const float* x, const float* w, const float* bias, const float* addend, float* y,
+                                      float* sum_out, int B, int cin, int cout, long V, void* stream) {
   HP_REQUIRE(x && w && y && cin <= 8 && cout <= 8, "hp_conv1x1_forward: at most 8 channels");
+  HP_REQUIRE((addend == nullptr) == (sum_out == nullptr), "hp_conv1x1_forward_sum: addend and sum_out go together");
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("conv1x1_fwd", st);
-  hipLaunchKernelGGL(k_conv1_fwd, dim3(ugrid((long)B * V)), dim3(UT), 0, st, x, w, bias, y, B, cin, cout, V);
+  hipLaunchKernelGGL(k_conv1_fwd, dim3(ugrid((long)B * V)), dim3(UT), 0, st, x, w, bias, y, B, cin, cout, V, addend, sum_out);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
 
 extern "C" int hp_conv1x1_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B,
                                    int cin, int cout, long V, void* stream) {
+  return hp_conv1x1_backward_sum(x, w, dy, nullptr, dx, dw, db, B, cin, cout, V, stream);
+}
+
+extern "C" int hp_conv1x1_backward_sum(const float* x, const float* w, const float* dy, const float* dy2, float* dx, float* dw,
+                                       float* db, int B, int cin, int cout, long V, void* stream) {
   HP_REQUIRE(x && w && dy && dx && dw, "hp_conv1x1_backward: null argument");
   if (!(cin == 4 && cout == 1)) {
     set_error("hp_conv1x1_backward: only the 4 -> 1 output convolution of UNet3d(1,4) is built (got %d -> %d)", cin, cout);
@@ -865,7 +881,7 @@ extern "C" int hp_conv1x1_backward(const float* x, const float* w, const float* 
   HP_CHECK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * cin * cout, st));
   if (db) HP_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * cout, st));
   HP_PROF("conv1x1_bwd", st);
-  hipLaunchKernelGGL((k_conv1_bwd<4, 1>), dim3(std::min(ugrid((long)B * V), 1024u)), dim3(UT), 0, st, x, w, dy, dx, dw, db, B, V);
+  hipLaunchKernelGGL((k_conv1_bwd<4, 1>), dim3(std::min(ugrid((long)B * V), 1024u)), dim3(UT), 0, st, x, w, dy, dx, dw, db, B, V, dy2);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

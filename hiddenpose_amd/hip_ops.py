@@ -378,6 +378,54 @@ class _Conv1x1(torch.autograd.Function):
         return dx, dw, db
 
 
+class _Conv1x1Sum(torch.autograd.Function):
+    """(conv1x1(x), conv1x1(x) + addend) in one pass; the backward adds the two incoming gradients of the convolution's
+    output on load (row U2: `feature + refine` has no launch of its own in either direction)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, addend):
+        x, addend = x.contiguous(), addend.contiguous()
+        b, cin = x.shape[:2]
+        cout = w.shape[0]
+        V = x.numel() // (b * cin)
+        y = torch.empty((b, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        assert addend.shape == y.shape
+        s = torch.empty_like(y)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_conv1x1_forward_sum(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), addend.data_ptr(), y.data_ptr(),
+                                                         s.data_ptr(), b, cin, cout, V, _stream(x)), "hp_conv1x1_forward_sum")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y, s
+
+    @staticmethod
+    def backward(ctx, dy, dsum):
+        x, w = ctx.saved_tensors
+        if dy is None and dsum is None:
+            return None, None, None, None
+        g1, g2 = (dy, dsum) if dy is not None else (dsum, None)
+        g1 = g1.contiguous()
+        g2 = g2.contiguous() if g2 is not None else None
+        b, cin = x.shape[:2]
+        cout = w.shape[0]
+        V = x.numel() // (b * cin)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_conv1x1_backward_sum(x.data_ptr(), w.data_ptr(), g1.data_ptr(), _lib.ptr(g2), dx.data_ptr(),
+                                                          dw.data_ptr(), _lib.ptr(db), b, cin, cout, V, _stream(x)),
+                       "hp_conv1x1_backward_sum")
+        return dx, dw, db, dsum
+
+
+def conv3d_sum(x, w, b, addend):
+    """(conv(x), conv(x) + addend) for the 1x1x1 output convolution of UNet3d."""
+    _need_cuda(x, "unet3d")
+    assert tuple(w.shape[2:]) == (1, 1, 1)
+    return _Conv1x1Sum.apply(x, w, b, addend)
+
+
 def conv3d(x, w, b=None, stride=1, padding=0):
     """1x1x1 convolution (UNet3d `Out`, unet/unet3d.py:65-71)."""
     assert tuple(w.shape[2:]) == (1, 1, 1) and stride == 1 and padding == 0

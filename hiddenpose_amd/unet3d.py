@@ -83,14 +83,22 @@ class UNet3d(nn.Module):
             setattr(self, name, kind(mi * n_channels, mo * n_channels))
         self.out = Out(n_channels, in_channels)
 
-    def forward(self, x):
+    def _body(self, x):
         skips = [self.conv(x)]
         for name in ("enc1", "enc2", "enc3", "enc4"):
             skips.append(getattr(self, name)(skips[-1]))
         y = skips.pop()
         for name in ("dec1", "dec2", "dec3", "dec4"):
             y = getattr(self, name)(y, skips.pop())
-        return self.out(y)
+        return y
+
+    def forward(self, x):
+        return self.out(self._body(x))
+
+    def forward_and_sum(self, x):
+        """(refined, x + refined): the sum the pose regressor reads (models/NlosPose.py:57) is written by the output
+        convolution's own pass."""
+        return K.conv3d_sum(self._body(x), self.out.conv.weight, self.out.conv.bias, x)
 
 
 def freeze_layer(model):

@@ -291,6 +291,13 @@ int hp_conv1x1_forward(const float* x, const float* w, const float* bias, float*
                        void* stream);
 int hp_conv1x1_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int cin,
                         int cout, long V, void* stream);
+/* The same convolution with the sum `y + addend` written in the same pass (models/NlosPose.py:57: `feature + refine`, the
+ * regressor's input, leaves with the refined volume), and its backward with a second incoming gradient dy2 of y (the one
+ * that arrives through that sum) added on load.  addend / sum_out and dy2 may be NULL. */
+int hp_conv1x1_forward_sum(const float* x, const float* w, const float* bias, const float* addend, float* y, float* sum_out,
+                           int B, int cin, int cout, long V, void* stream);
+int hp_conv1x1_backward_sum(const float* x, const float* w, const float* dy, const float* dy2, float* dx, float* dw, float* db,
+                            int B, int cin, int cout, long V, void* stream);
 
 /* ------------------------------------------------------------------------
  * Elementwise / reduction stages around the convolutions.
