@@ -443,21 +443,40 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     typedef __attribute__((address_space(3))) void* lptr_t;
     const unsigned short* const xh16 = (const unsigned short*)Xv;
     const unsigned short* const wh16 = (const unsigned short*)Wp;
+    const bool all_w = n0 + BN <= g.Nout;  // every weight row of this block's N tile exists (workgroup-uniform)
     // issue the loads of K tile (ld_tap, ld_ci) into buffer `buf`, then advance the running tile
     auto stage = [&](int buf) {
       __bf16* const ab = Ah + buf * GLBUF;
       __bf16* const bb = ab + BM * 64;
       const long xb = ld_xoff + ld_ci * BKT;
       const long wbo = ld_woff + ld_ci * BKT;
+      // Rows that need zeros (padding taps, rows past M / N_out) are rare: one wave-wide test decides whether the loads of
+      // this tile need the per-lane choice between the row and the zero row at all
+      const unsigned m4 = (unsigned)(vmask[0] & 1ull) & (unsigned)(vmask[1] & 1ull) & (unsigned)(vmask[2] & 1ull) &
+                          (unsigned)(vmask[3] & 1ull);
+      const unsigned short* const xt = xh16 + xb;
+      if (__builtin_amdgcn_ballot_w64(m4 == 0u) == 0ull) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const void* src = (vmask[i] & 1ull) ? (const void*)(xh16 + xb + rowoff[i]) : (const void*)g_zero_row;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ab + (i * 32 + wave * 8) * 64), 16, 0, 0);
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(xt + rowoff[i]), (lptr_t)(ab + (i * 32 + wave * 8) * 64), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const void* src = (vmask[i] & 1ull) ? (const void*)(xt + rowoff[i]) : (const void*)g_zero_row;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ab + (i * 32 + wave * 8) * 64), 16, 0, 0);
+        }
       }
+      const unsigned short* const wt = wh16 + wbo;
+      if (all_w) {
 #pragma unroll
-      for (int i = 0; i < BN / 32; ++i) {
-        const void* src = wvalid[i] ? (const void*)(wh16 + wbo + wrow[i]) : (const void*)g_zero_row;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bb + (i * 32 + wave * 8) * 64), 16, 0, 0);
+        for (int i = 0; i < BN / 32; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(wt + wrow[i]), (lptr_t)(bb + (i * 32 + wave * 8) * 64), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+          const void* src = wvalid[i] ? (const void*)(wt + wrow[i]) : (const void*)g_zero_row;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bb + (i * 32 + wave * 8) * 64), 16, 0, 0);
+        }
       }
       if (++ld_ci == kpt) {
         ld_ci = 0;
