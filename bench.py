@@ -7,7 +7,10 @@ synthetic 128x128x512 transients, batch 4 per GPU, fp32 (BASELINE.json configs[1
 
 One process per GPU; for N > 1 gradients are averaged with bucketed RCCL all-reduce
 overlapped with backward (hiddenpose_amd/data_parallel.py).  Per-GPU batch is fixed,
-so scaling is weak.  Rank 0 prints ONE JSON line.
+so scaling is weak.  Rank 0 prints ONE JSON line.  Started WITHOUT a launcher (no WORLD_SIZE
+in the environment) and --gpus N > 1, this process starts the N ranks itself -- fresh child
+processes under torch.distributed.run, before anything here has touched the GPU -- relays
+their output and exits with their status.
 
 Extra objects on the line:
   roofline     -- the dominant hand-written HIP kernel of the timed region, timed with HIP
@@ -211,7 +214,7 @@ def cpu_baseline(threads: int, full: bool = False):
                       f"forward + losses + backward + Adam {t_train:.2f} s (medians of 3 after 1 warm-up); value = train leg / 4"}
 
 
-def bench_sformer(args):
+def bench_sformer(args, emit=True):
     """BASELINE config 5: NlosPoseSformer (dim 256, depth 8, 8 heads x 32, patch 4, 16 frames of 128x128), batch 8,
     forward only (the reference has no training loop for this head), fp32 MFMA attention."""
     from hiddenpose_amd import _lib
@@ -224,7 +227,7 @@ def bench_sformer(args):
               dim_head=32, out_dim=512)
     model = NlosPoseSformer(**kw).cuda().eval()
     model.linear_precision = args.conv_precision  # fp32 (default) or a bf16 matrix-core mode for the Linear GEMMs
-    model.attention_precision = "bf16" if args.conv_precision == "bf16" else "fp32"
+    model.attention_precision = getattr(args, "attention", None) or ("bf16" if args.conv_precision == "bf16" else "fp32")
     video = torch.rand(B, 16, 1, 128, 128, device="cuda")
     for _ in range(args.warmup):
         model(video)
@@ -242,20 +245,23 @@ def bench_sformer(args):
     attn_flops = 8 * (B * 8 * 16 * 1024 * (24 + 1024) * 32 * 4 + B * 8 * 24 * ntok * 32 * 4)
     ms = prof.get("sformer_attention_patch", (0, 0.0))[1] + prof.get("sformer_attention_joint", (0, 0.0))[1]
     ach = attn_flops * args.steps / (ms / 1e3) / 1e12 if ms else None
-    apeak = MFMA_BF16_PEAK_TFLOPS if model.attention_precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-    print(json.dumps({
+    apeak = MFMA_F32_PEAK_TFLOPS if model.attention_precision == "fp32" else MFMA_BF16_PEAK_TFLOPS
+    line = {
         "metric": "samples/sec NlosPoseSformer forward (config 5)", "value": round(B * args.steps / dt, 3), "unit": "samples/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.conv_precision == "fp32" else
-                 "bf16 linears + bf16 patch attention (f32 soft-max)" if args.conv_precision == "bf16" else
-                 f"{args.conv_precision} linears, f32 attention", "data": "synthetic",
+        "dtype": "f32" if (args.conv_precision == "fp32" and model.attention_precision == "fp32") else
+                 f"{args.conv_precision} linears + {model.attention_precision} patch attention (MFMA, f32 soft-max and accumulation)",
+        "data": "synthetic",
         "config": {"workload": f"NlosPoseSformer forward, batch {B}, 16 frames x 128x128, patch 4, dim 256, depth 8, "
                                "8 heads x 32, random-init weights"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())},
         "roofline": {"kernel": "sformer_attention", "bound": "mfma", "achieved": round(ach, 2) if ach else None,
                      "peak": apeak, "unit": "TFLOP/s", "frac": round(ach / apeak, 4) if ach else None,
-                     "traffic": None}}), flush=True)
+                     "traffic": None}}
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def bench_ingest(args):
@@ -321,7 +327,7 @@ def bench_ingest(args):
     print(json.dumps(line), flush=True)
 
 
-def bench_highres(args):
+def bench_highres(args, emit=True):
     """BASELINE config 4: 256x256x1024 transient, FeatureExtraction -> LCT -> normalize -> UNet3d only
     (forward + backward w.r.t. the FE / UNet parameters), batch 1, HBM-bandwidth roofline of the LCT."""
     from hiddenpose_amd import _lib
@@ -368,7 +374,7 @@ def bench_highres(args):
     ach_moved = moved * lct_calls / (lct_ms / 1e3) / 1e9 if lct_ms else None
     conv_ms = sum(v[1] for k, v in prof.items() if k.startswith("dconv3_")) / args.steps
     conv_gflop = 3 * 410.0 * B   # FE + U-Net convolutions forward 410.0 GFLOP at 1024 x 256 x 256; backward = 2x
-    print(json.dumps({
+    line = {
         "metric": "samples/sec (256x256x1024 meas) FE+LCT+normalize+UNet fwd+bwd", "value": round(B * args.steps / dt, 3),
         "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -383,38 +389,95 @@ def bench_highres(args):
                      "ms_per_direction": round(lct_ms / lct_calls, 3) if lct_ms else None},
         "thin_channel_convolutions": {"ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": conv_gflop,
                                       "achieved_tflops": round(conv_gflop / conv_ms, 1) if conv_ms else None,
-                                      "peak_tflops": MFMA_F32_PEAK_TFLOPS}}), flush=True)
+                                      "peak_tflops": MFMA_F32_PEAK_TFLOPS}}
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
-def quick_native(args, local, note, workload="native", precision=None, label="reference-native shape"):
+def quick_native(args, local, note, workload="native", precision=None, label="reference-native shape", dist_ctx=None,
+                 batch=None):
     """The same train step at another shape / arithmetic (default: the reference's native 128x128x128, batch 4),
-    1 warm-up + 3 timed steps."""
+    1 warm-up + 3 timed steps.  `dist_ctx` = (rank, world, algo, bucket_mb): every rank runs it with its own samples and a
+    bf16-wire gradient exchange, the timed region is bracketed by barriers and the slowest rank's time counts."""
     from hiddenpose_amd import testing as hpt
     from hiddenpose_amd.config import make_cfg
     from hiddenpose_amd.NlosPose import NlosPose
     from hiddenpose_amd.train_epoch import build_training, train_step
 
     T, N, B = WORKLOADS[workload]
+    B = batch or B
     precision = precision or args.conv_precision
     dev = torch.device("cuda", local)
     cfg = make_cfg(T, N, device=local, conv_precision=precision)
     model = NlosPose(cfg).to(dev).train()
     criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
-    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410).to(dev)
-    vol = hpt.synthetic_vol(B, T, N, seed=1).to(dev)
-    joints = hpt.synthetic_joints(B, T // 2, seed=2).to(dev)
-    train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, None)
+    rank, world, reducer = 0, 1, None
+    if dist_ctx is not None:
+        import torch.distributed as dist
+
+        from hiddenpose_amd.data_parallel import GradBucketReducer
+
+        rank, world, algo, bucket_mb = dist_ctx
+        wire = torch.bfloat16 if precision != "fp32" else None
+        reducer = GradBucketReducer(model, bucket_mb=bucket_mb, algo=algo, wire_dtype=wire)
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410 + rank * B).to(dev)
+    vol = hpt.synthetic_vol(B, T, N, seed=1 + rank).to(dev)
+    joints = hpt.synthetic_joints(B, T // 2, seed=2 + rank).to(dev)
+    train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
-        train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, None)
+        train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    note(f"extra: {N}x{N}x{T} batch {B} {precision}: {1e3 * dt / steps:.1f} ms/step")
-    return {"workload": f"NlosPose train step, {N}x{N}x{T} ({label}), batch {B}, {precision}",
-            "ms_per_step": round(1e3 * dt / steps, 3), "value": round(B * steps / dt, 3), "unit": "samples/s", "steps": steps,
-            "warmup": 1}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if reducer is not None:
+        reducer.remove_hooks()
+    note(f"extra: {N}x{N}x{T} batch {B}/GPU x {world} {precision}: {1e3 * dt / steps:.1f} ms/step")
+    out = {"workload": f"NlosPose train step, {N}x{N}x{T} ({label}), batch {B}" + ("/GPU" if world > 1 else "") + f", {precision}",
+           "ms_per_step": round(1e3 * dt / steps, 3), "value": round(B * world * steps / dt, 3), "unit": "samples/s", "steps": steps,
+           "warmup": 1}
+    if world > 1:
+        out.update({"n_gpus": world, "global_batch": B * world,
+                    "parallelism": f"dp{world} ({dist_ctx[2]}, {'bf16' if precision != 'fp32' else 'fp32'} wire)"})
+    return out
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (torch.distributed.run,
+    rendezvous on 127.0.0.1 and a free port), before THIS process has made any GPU call; their stdout / stderr are
+    inherited, so rank 0's JSON line is this command's JSON line.  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+    print(f"[bench] no launcher in the environment: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def device_identity(local: int) -> dict:
+    pr = torch.cuda.get_device_properties(local)
+    uuid = getattr(pr, "uuid", None)
+    return {"device_index": local, "name": pr.name, "uuid": str(uuid) if uuid is not None else None,
+            "pci_bus_id": getattr(pr, "pci_bus_id", None), "pid": os.getpid()}
 
 
 def main():
@@ -429,6 +492,9 @@ def main():
                     help="regressor convolution GEMM arithmetic; bf16s = BASELINE.json configs[2] in full (bf16 matrix cores and "
                          "bf16 activation storage, fp32 LCT / statistics / weights); bf16 = bf16 matrix cores over fp32 tensors. "
                          "The headline metric (configs[1]) is fp32, the default.")
+    ap.add_argument("--attention", default=None, choices=["fp32", "bf16", "fp16"],
+                    help="--workload sformer: arithmetic of the per-frame patch attention (BASELINE configs[4] words it "
+                         "'MFMA fp16 attention'); default follows --conv-precision")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="opt-in: weight gradients on a second HIP stream (hip_ops.set_wgrad_async). "
@@ -450,12 +516,12 @@ def main():
         return bench_highres(args)
     if args.workload == "ingest":
         return bench_ingest(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))  # nothing above touches the GPU (importing torch does not initialise HIP)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # rehearsal hook (single-GPU boxes): HP_DIST_BACKEND=gloo HP_SHARE_GPU=1 runs all ranks on cuda:0 over gloo
@@ -509,6 +575,8 @@ def main():
     vol = hpt.synthetic_vol(B, T, N, seed=1 + rank).to(dev)
     joints = hpt.synthetic_joints(B, T // 2, seed=2 + rank).to(dev)
 
+    reducer_on = reducer is not None
+
     def step():
         return train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
 
@@ -553,10 +621,25 @@ def main():
     for k, (n1, ms1) in _lib.profile_read().items():
         if k not in prof:
             prof[k] = (n1 * args.steps, ms1 * args.steps)
+    ranks_seen = [device_identity(local)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # evidence that the collectives really spanned `world` processes on distinct devices
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, dict(device_identity(local), rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0"))))
+    dist_extra = None
+    if world > 1 and args.workload == "t512" and not args.no_extra and args.conv_precision == "fp32":
+        # BASELINE configs[2]: batch 32 = 8 x 4 in bf16 (matrix cores + activation storage) with fp32 LCT, bf16 on the wire;
+        # at other world sizes the same per-GPU share
+        if reducer is not None:
+            reducer.remove_hooks()
+        del step
+        model = optimizer = criterion = voxel_criterion = meas = vol = joints = reducer = None
+        torch.cuda.empty_cache()
+        dist_extra = quick_native(args, local, note, "t512", "bf16s", "headline cube, configs[2] arithmetic, storage and wire",
+                                  dist_ctx=(rank, world, args.dp_algo, args.bucket_mb))
 
     if rank == 0:
         samples = B * world * args.steps
@@ -570,9 +653,11 @@ def main():
                                    f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
                                    "accumulation) with fp32 LCT, U-Net, norms, losses and " + ("bf16 regressor activations / activation gradients in HBM (fp32 raw conv outputs, statistics, weights)" if args.conv_precision == "bf16s" else "fp32 tensors in HBM") if bf16 else "fp32") + ", random-init weights"
                                    + (", weight gradients on a second stream (kernels overlap)" if args.wgrad_stream and world == 1 else ""),
-                       "global_batch": B * world,
+                       "global_batch": B * world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "exchange": args.dp_algo if reducer_on else None, "ranks": ranks_seen,
                        "parallelism": f"dp{world}" + (f" ({args.dp_algo}, {'bf16' if wire is not None else 'fp32'} wire, "
-                                                      f"{args.bucket_mb:g} MB buckets)" if reducer is not None else ""), "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
+                                                      f"{args.bucket_mb:g} MB buckets)" if reducer_on else ""), "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
                        "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
             "loss": round(float(loss.item()), 6),
             # the same synthetic batch every step, Adam lr 1e-3 from the reference's initialisation: the loss must move
@@ -623,6 +708,8 @@ def main():
             line["mfma_tflops_by_kernel"] = {k: round(cf[k] * args.steps / (prof[k][1] / 1e3) / 1e12, 1)
                                              for k in sorted(cf) if k in prof and prof[k][1] > 0}
         line["roofline"] = roof
+        if dist_extra is not None:
+            line["extra"] = {"configs2_bf16s_dp": dist_extra}
         if world == 1 and args.workload == "t512" and not args.no_extra:
             # SURVEY 8(d) names two shapes for configs[1]: the BASELINE-worded 128x128x512 cube (the headline above) and
             # the reference's own training shape 128^3 (train.py:77-86); the second is reported here, same step, same batch
@@ -635,6 +722,20 @@ def main():
                 torch.cuda.empty_cache()
                 line["extra"]["configs2_bf16s"] = quick_native(args, local, note, "t512", "bf16s",
                                                               "headline cube, configs[2] arithmetic and storage")
+                # BASELINE configs[3] and configs[4] on the same driver line (short runs; their own workloads give the long form)
+                torch.cuda.empty_cache()
+                sub = argparse.Namespace(**vars(args))
+                sub.steps, sub.warmup, sub.batch = 3, 1, 0
+                hr = bench_highres(sub, emit=False)
+                line["extra"]["configs3_highres"] = {k: hr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
+                                                                        "config", "roofline", "thin_channel_convolutions")}
+                note(f"extra: highres {hr['ms_per_step']:.1f} ms/step")
+                torch.cuda.empty_cache()
+                sub.conv_precision, sub.attention = "bf16", "fp16"
+                sf = bench_sformer(sub, emit=False)
+                line["extra"]["configs4_sformer_fp16"] = {k: sf[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
+                                                                             "dtype", "config", "roofline")}
+                note(f"extra: sformer {sf['ms_per_step']:.1f} ms/step")
         if world == 1 and not args.no_cpu_baseline:
             # the box's CPU share for one GPU is 16 cores: more threads than that only oversubscribe
             try:
@@ -646,7 +747,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(threads, full=args.cpu_baseline_full)
             note("cpu_baseline done")
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -79,7 +79,7 @@ class NlosPoseSformer(nn.Module):
     # arithmetic of the transformer-layer Linear GEMMs: "fp32" (exact, default) or the bf16 matrix-core modes of
     # hp_conv_desc.precision; attention, LayerNorm, GEGLU, patch embedding and the output head stay fp32
     linear_precision = "fp32"
-    # patch-token attention: "fp32" (exact-fp32 MFMA, default) or "bf16" (bf16 matrix cores, fp32 soft-max; dim_head 32)
+    # patch-token attention: "fp32" (exact-fp32 MFMA, default), "bf16" or "fp16" (16-bit matrix cores, fp32 soft-max; dim_head 32)
     attention_precision = "fp32"
 
     def __init__(self, *, dim, num_frames, num_joints=24, image_size=224, patch_size=16, channels=2, depth=12, heads=8,
@@ -116,9 +116,9 @@ class NlosPoseSformer(nn.Module):
         dev = video.device
         st = _lib.current_stream_handle(dev)
         prec = _LINEAR_PRECISION[self.linear_precision]
-        aprec = {"fp32": 0, "bf16": 1}[self.attention_precision]
+        aprec = {"fp32": 0, "bf16": 1, "fp16": 4}[self.attention_precision]
         if aprec and dh != 32:
-            raise _lib.HiddenPoseHipError("bf16 attention is built for dim_head 32 only")
+            raise _lib.HiddenPoseHipError("bf16 / fp16 attention is built for dim_head 32 only")
         with torch.cuda.device(dev):
             tokens = torch.empty(b * f * n, ps * ps * c, dtype=torch.float32, device=dev)
             _lib.check(L.hp_sformer_patchify(video.data_ptr(), tokens.data_ptr(), b, f, c, H, W, ps, st), "hp_sformer_patchify")

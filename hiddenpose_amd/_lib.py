@@ -31,7 +31,10 @@ SIGNATURES = {
     "hp_profile_get": (_i, [_i, C.c_char_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "hp_lct_host_constants": (_i, [_i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hp_lct_plan_create": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i]),
+    "hp_lct_plan_create_mode": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i, _i]),
     "hp_lct_plan_destroy": (_i, [_vp]),
+    "hp_laplacian5_forward": (_i, [_fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
+    "hp_laplacian5_backward": (_i, [_fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_lct_workspace_bytes": (_sz, [_vp, _i]),
     "hp_lct_forward": (_i, [_vp, _fp, _fp, _i, _vp, _sz, _vp]),
     "hp_lct_backward": (_i, [_vp, _fp, _fp, _i, _vp, _sz, _vp]),
@@ -107,6 +110,8 @@ SIGNATURES = {
     "hp_sformer_attention_workspace_bytes": (_sz, [_i, _i, _i]),
     "hp_lct_time_window": (_i, [_fp, _fp, _i, _i, _i, _i, C.c_long, C.POINTER(C.c_int), _i, _vp]),
     "hp_rgbe_decode": (_i, [_vp, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _sz]),
+    "hp_ingest_rgbe_to_gray": (_i, [_vp, C.c_long, _fp, _fp, _vp]),
+    "hp_ingest_image_to_meas": (_i, [_fp, _i, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "hp_ingest_rgbe_to_meas": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _fp, _vp]),
     "hp_box_downsample_round": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),
     "hp_pair_average_axis0": (_i, [_fp, _fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _vp]),

@@ -188,6 +188,67 @@ static int parse_header(Cursor& c, int& W, int& H) {
   return HP_OK;
 }
 
+
+// ---------------------------------------------------------------- noise variant (utils/nlos_pose_dataloader_noise.py:86-118)
+// The noise dataset converts the RAW float image to gray (its first "/ max" is commented out, :92), perturbs it
+// (addnoise_dataset: hp_noise_blur_poisson) and only then normalises by the global maximum of the noisy image, so the gray
+// image exists in memory between two kernels:
+//   k_rgbe_gray_raw      RGBE bytes -> gray (0.114 B + 0.587 G) + 0.299 R of the decoded floats, and the :88 maximum
+//   k_image_max          maximum of the perturbed image (values >= 0)
+//   k_image_to_meas<R>   / max, '(t h) w -> t h w'[:keep], time pairs and the box rounds.  R = double when the image
+//                        holds Poisson counts (numpy: int64 / int64 max -> float64, averaged in float64, cast at the
+//                        end), float for a blur-only image (float32 throughout)
+__global__ __launch_bounds__(256) void k_rgbe_gray_raw(const unsigned* __restrict__ px, long n, float* __restrict__ gray,
+                                                       float* __restrict__ mx) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned p = px[i];
+    const float f = rgbe_scale(p >> 24);
+    const float r = __fmul_rn((float)(p & 255u), f), g = __fmul_rn((float)((p >> 8) & 255u), f),
+                b = __fmul_rn((float)((p >> 16) & 255u), f);
+    gray[i] = __fadd_rn(__fadd_rn(__fmul_rn(0.114f, b), __fmul_rn(0.587f, g)), __fmul_rn(0.299f, r));
+    m = fmaxf(m, fmaxf(fmaxf(r, g), b));
+  }
+  block_max_to(m, mx);
+}
+
+__global__ __launch_bounds__(256) void k_image_max(const float* __restrict__ x, long n, float* __restrict__ mx) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, x[i]);
+  block_max_to(m, mx);
+}
+
+template <typename R, int L>
+__device__ __forceinline__ R image_pyramid(const float* __restrict__ img, const IngestGeom& g, R mx, int t, int h, int w) {
+  if constexpr (L == 0) {
+    const long row = (long)g.H * g.W;
+    const long o = (long)(2 * t) * row + (long)h * g.W + w;
+    return ((R)img[o] / mx + (R)img[o + row] / mx) / (R)2;
+  } else {
+    R vw[2];
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+      R vh[2];
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+        vh[dh] = (image_pyramid<R, L - 1>(img, g, mx, 2 * t, 2 * h + dh, 2 * w + dw) +
+                  image_pyramid<R, L - 1>(img, g, mx, 2 * t + 1, 2 * h + dh, 2 * w + dw)) / (R)2;
+      vw[dw] = (vh[0] + vh[1]) / (R)2;
+    }
+    return (vw[0] + vw[1]) / (R)2;
+  }
+}
+
+template <typename R, int CNT>
+__global__ __launch_bounds__(256) void k_image_to_meas(const float* __restrict__ img, float* __restrict__ out, IngestGeom g,
+                                                       const float* __restrict__ mx) {
+  const long n = (long)g.To * g.Ho * g.Wo;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int w = (int)(i % g.Wo), h = (int)((i / g.Wo) % g.Ho), t = (int)(i / ((long)g.Wo * g.Ho));
+  out[i] = (float)image_pyramid<R, CNT>(img, g, (R)mx[0], t, h, w);
+}
+
 }  // namespace hp
 
 using namespace hp;
@@ -297,6 +358,52 @@ extern "C" int hp_pair_average_axis0(const float* in, float* out, int D, int H, 
   HP_PROF("ingest_pair_avg", st);
   hipLaunchKernelGGL(k_pair_avg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, D / 2, H, W, stride_d, stride_h,
                      stride_w);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_ingest_rgbe_to_gray(const unsigned char* rgbe, long npx, float* gray, float* maxima, void* stream) {
+  HP_REQUIRE(rgbe && gray && maxima && npx > 0, "hp_ingest_rgbe_to_gray: bad argument");
+  HP_REQUIRE(((uintptr_t)rgbe & 3) == 0, "ingest: RGBE buffer must be 4-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  HP_CHECK_HIP(hipMemsetAsync(maxima, 0, sizeof(float), st));
+  const unsigned nb = (unsigned)std::min<long>((npx + 255) / 256, 256 * 16);
+  HP_PROF("ingest_rgbe_gray", st);
+  hipLaunchKernelGGL(k_rgbe_gray_raw, dim3(nb), dim3(256), 0, st, (const unsigned*)rgbe, npx, gray, maxima);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_ingest_image_to_meas(const float* image, int frames, int H, int W, int keep_frames, int downsample_cnt,
+                                       int float64, float* meas, float* maxima, void* stream) {
+  HP_REQUIRE(image && meas && maxima, "hp_ingest_image_to_meas: null argument");
+  HP_REQUIRE(frames >= 1 && H >= 1 && W >= 1 && keep_frames >= 2 && keep_frames <= frames, "ingest: bad frame counts");
+  HP_REQUIRE(downsample_cnt >= 0 && downsample_cnt <= 2, "ingest: downsample_cnt must be 0, 1 or 2 (got %d)", downsample_cnt);
+  const int div = 1 << downsample_cnt;
+  HP_REQUIRE(keep_frames % (2 * div) == 0 && H % div == 0 && W % div == 0,
+             "ingest: %d frames x %d x %d is not divisible by the averaging pyramid", keep_frames, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  const long npx = (long)frames * H * W;
+  HP_CHECK_HIP(hipMemsetAsync(maxima, 0, sizeof(float), st));
+  const unsigned nb = (unsigned)std::min<long>((npx + 255) / 256, 256 * 16);
+  {
+    HP_PROF("ingest_image_max", st);
+    hipLaunchKernelGGL(k_image_max, dim3(nb), dim3(256), 0, st, image, npx, maxima);
+  }
+  IngestGeom g{H, W, keep_frames / (2 * div), H / div, W / div};
+  const long nout = (long)g.To * g.Ho * g.Wo;
+  const dim3 ob((unsigned)((nout + 255) / 256)), tb(256);
+  {
+    HP_PROF("ingest_image_to_meas", st);
+#define HP_I2M(R_)                                                                                                  \
+  switch (downsample_cnt) {                                                                                         \
+    case 0: hipLaunchKernelGGL((k_image_to_meas<R_, 0>), ob, tb, 0, st, image, meas, g, maxima); break;             \
+    case 1: hipLaunchKernelGGL((k_image_to_meas<R_, 1>), ob, tb, 0, st, image, meas, g, maxima); break;             \
+    default: hipLaunchKernelGGL((k_image_to_meas<R_, 2>), ob, tb, 0, st, image, meas, g, maxima); break;            \
+  }
+    if (float64) { HP_I2M(double) } else { HP_I2M(float) }
+#undef HP_I2M
+  }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

@@ -158,7 +158,7 @@ static void fft1d(std::complex<double>* a, int n, int stride, const std::complex
   }
 }
 
-void lct_invpsf_slice(const LctHost& h, int kz, std::complex<double>* out, std::complex<double>* work) {
+void lct_invpsf_slice(const LctHost& h, int kz, std::complex<double>* out, std::complex<double>* work, bool wiener) {
   const int N2 = 2 * h.N, M2 = 2 * h.T;
   const double PI = 3.14159265358979323846;
   // twiddles / bit reversal for the 2N-point transforms (small; rebuilt per call)
@@ -192,7 +192,7 @@ void lct_invpsf_slice(const LctHost& h, int kz, std::complex<double>* out, std::
   for (int p = 0; p < N2 * N2; ++p) {
     std::complex<double> f = out[p];
     double den = inv_snr + f.real() * f.real() + f.imag() * f.imag();
-    out[p] = std::conj(f) / den;
+    out[p] = wiener ? std::conj(f) / den : std::conj(f);
   }
 }
 

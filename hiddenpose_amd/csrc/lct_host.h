@@ -31,8 +31,8 @@ struct LctHost {
 void lct_host_build(int T, int N, double bin_len, double wall_size, LctHost& out);
 
 // One kz slice (2N x 2N, natural frequency order, row-major [kx][ky]) of
-// invpsf = conj(F)/(1/snr + |F|^2), F = fftn(psf) in double precision.
-// `work` must hold 2 * (2N)^2 complex<double>.
-void lct_invpsf_slice(const LctHost& h, int kz, std::complex<double>* out, std::complex<double>* work);
+// invpsf = conj(F)/(1/snr + |F|^2) (mode 'lct') or conj(F) (mode 'bp', feature_propagation.py:93-94),
+// F = fftn(psf) in double precision.  `work` is unused (kept for callers that size a scratch buffer).
+void lct_invpsf_slice(const LctHost& h, int kz, std::complex<double>* out, std::complex<double>* work, bool wiener = true);
 
 }  // namespace hp

@@ -826,7 +826,13 @@ extern "C" int hp_lct_host_constants(int T, int N, double bin_len, double wall_s
 
 extern "C" int hp_lct_plan_create(hp_lct_plan** out, int T, int N, double bin_len, double wall_size, int material,
                                   int device) {
+  return hp_lct_plan_create_mode(out, T, N, bin_len, wall_size, material, HP_LCT_MODE_LCT, device);
+}
+
+extern "C" int hp_lct_plan_create_mode(hp_lct_plan** out, int T, int N, double bin_len, double wall_size, int material,
+                                       int mode, int device) {
   HP_REQUIRE(out, "hp_lct_plan_create: null out");
+  HP_REQUIRE(mode == HP_LCT_MODE_LCT || mode == HP_LCT_MODE_BP, "hp_lct_plan_create: bad mode %d", mode);
   *out = nullptr;
   if (!supported_len(T) || !supported_len(N)) {
     set_error("hp_lct_plan_create: T and N must be powers of two in [16,1024] (got T=%d N=%d)", T, N);
@@ -907,7 +913,7 @@ extern "C" int hp_lct_plan_create(hp_lct_plan** out, int T, int N, double bin_le
       th.emplace_back([&, t]() {
         std::vector<std::complex<double>> buf(sl);
         for (int at = (int)t; at < M2; at += (int)nth) {
-          lct_invpsf_slice(hh, pT[at], buf.data(), nullptr);
+          lct_invpsf_slice(hh, pT[at], buf.data(), nullptr, mode == HP_LCT_MODE_LCT);
           float2* dst = hostH.data() + (size_t)at * sl;
           for (int ah = 0; ah < N2; ++ah) {
             const std::complex<double>* src = buf.data() + (size_t)pN[ah] * N2;

@@ -416,6 +416,88 @@ __global__ __launch_bounds__(MT) void k_blur1d_poisson(const float* __restrict__
   y[o] = do_poisson ? hp_poisson(s, seed, (unsigned long long)o) : s;
 }
 
+// ---------------------------------------------------------------- 'bp' mode epilogue (models/feature_propagation.py:246-253)
+// volume -> ReplicationPad3d(2) -> conv3d with the 5^3 Laplacian-of-Gaussian filter (utils/helper.py:13-32) -> first time
+// slice zeroed.  One input channel, one output channel: a 125-tap stencil.  A workgroup owns an 4 x 8 x 32 output tile and
+// stages its 8 x 12 x 36 halo (indices clamped = replication padding) in LDS once; the 125 weights sit in LDS as well.
+constexpr int LP_Z = 4, LP_Y = 8, LP_X = 32, LP_R = 2;
+constexpr int LP_HZ = LP_Z + 2 * LP_R, LP_HY = LP_Y + 2 * LP_R, LP_HX = LP_X + 2 * LP_R, LP_PX = LP_HX + 1;
+__global__ __launch_bounds__(256) void k_laplacian5_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, int T, int H, int W, int tz, int ty, int tx) {
+  __shared__ float tile[LP_HZ * LP_HY * LP_PX];
+  __shared__ float wt[125];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int bx = b % tx;
+  b /= tx;
+  const int by = b % ty;
+  b /= ty;
+  const int bz = b % tz;
+  const long plane = b / tz;
+  const float* xp = x + plane * (long)T * H * W;
+  float* yp = y + plane * (long)T * H * W;
+  const int z0 = bz * LP_Z, y0 = by * LP_Y, x0 = bx * LP_X;
+  if (tid < 125) wt[tid] = w[tid];
+  for (int i = tid; i < LP_HZ * LP_HY * LP_HX; i += 256) {
+    const int hx = i % LP_HX, hy = (i / LP_HX) % LP_HY, hz = i / (LP_HX * LP_HY);
+    const int gz = min(max(z0 + hz - LP_R, 0), T - 1), gy = min(max(y0 + hy - LP_R, 0), H - 1), gx = min(max(x0 + hx - LP_R, 0), W - 1);
+    tile[(hz * LP_HY + hy) * LP_PX + hx] = xp[((long)gz * H + gy) * W + gx];
+  }
+  __syncthreads();
+  const int lx = tid & 31, ly = tid >> 5;
+  const int ox = x0 + lx, oy = y0 + ly;
+  if (ox >= W || oy >= H) return;
+#pragma unroll
+  for (int lz = 0; lz < LP_Z; ++lz) {
+    const int oz = z0 + lz;
+    if (oz >= T) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 5; ++bb)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc = fmaf(wt[(a * 5 + bb) * 5 + c], tile[((lz + a) * LP_HY + ly + bb) * LP_PX + lx + c], acc);
+    yp[((long)oz * H + oy) * W + ox] = oz == 0 ? 0.f : acc;   // volumn[:, :1] = 0 (:252)
+  }
+}
+
+// adjoint of the same map: gx[i] = sum over the padded positions p that replicate voxel i (p = i inside; the two positions
+// beyond the border as well for a border voxel, per axis) of sum_tap w[tap] * g[p - tap + 2], g taken as 0 outside the volume
+// and in its first time slice.  A gather: no atomics, run-to-run identical.
+__global__ __launch_bounds__(256) void k_laplacian5_bwd(const float* __restrict__ g, const float* __restrict__ w,
+                                                        float* __restrict__ gx, int T, int H, int W, long total) {
+  __shared__ float wt[125];
+  if (threadIdx.x < 125) wt[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ix = (int)(i % W), iy = (int)((i / W) % H), iz = (int)((i / ((long)W * H)) % T);
+  const float* gp = g + (i / ((long)T * H * W)) * (long)T * H * W;
+  const int pz0 = iz == 0 ? -LP_R : iz, pz1 = iz == T - 1 ? T - 1 + LP_R : iz;
+  const int py0 = iy == 0 ? -LP_R : iy, py1 = iy == H - 1 ? H - 1 + LP_R : iy;
+  const int px0 = ix == 0 ? -LP_R : ix, px1 = ix == W - 1 ? W - 1 + LP_R : ix;
+  float acc = 0.f;
+  for (int pz = pz0; pz <= pz1; ++pz)
+    for (int py = py0; py <= py1; ++py)
+      for (int px = px0; px <= px1; ++px)
+        for (int a = 0; a < 5; ++a) {
+          const int oz = pz - a + LP_R;   // output voxel whose tap a reads padded position pz
+          if (oz < 1 || oz >= T) continue;  // slice 0 of the output is zeroed: its gradient does not flow
+          for (int b = 0; b < 5; ++b) {
+            const int oy = py - b + LP_R;
+            if (oy < 0 || oy >= H) continue;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+              const int ox = px - c + LP_R;
+              if (ox < 0 || ox >= W) continue;
+              acc = fmaf(wt[(a * 5 + b) * 5 + c], gp[((long)oz * H + oy) * W + ox], acc);
+            }
+          }
+        }
+  gx[i] = acc;
+}
+
 static unsigned mgrid(long n) { return (unsigned)std::max<long>(1, std::min<long>((n + MT - 1) / MT, 256 * 8)); }
 
 }  // namespace hp
@@ -581,6 +663,29 @@ extern "C" int hp_noise_blur_poisson(const float* x, float* y, long n, const flo
   HP_PROF("noise_blur_poisson", st);
   const size_t shm = sizeof(float) * (size_t)(2 * radius + 1 + MT + 2 * radius);
   hipLaunchKernelGGL(k_blur1d_poisson, dim3((unsigned)((n + MT - 1) / MT)), dim3(MT), shm, st, x, y, n, taps, radius, do_poisson, seed);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_laplacian5_forward(const float* x, const float* w125, float* y, long planes, int T, int H, int W, void* stream) {
+  HP_REQUIRE(x && w125 && y && planes > 0 && T >= 1 && H >= 1 && W >= 1, "hp_laplacian5_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int tz = (T + LP_Z - 1) / LP_Z, ty = (H + LP_Y - 1) / LP_Y, tx = (W + LP_X - 1) / LP_X;
+  const long blocks = planes * tz * ty * tx;
+  HP_REQUIRE(blocks < (1l << 31), "hp_laplacian5_forward: too many tiles");
+  HP_PROF("laplacian5_fwd", st);
+  hipLaunchKernelGGL(k_laplacian5_fwd, dim3((unsigned)blocks), dim3(256), 0, st, x, w125, y, T, H, W, tz, ty, tx);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_laplacian5_backward(const float* dy, const float* w125, float* dx, long planes, int T, int H, int W, void* stream) {
+  HP_REQUIRE(dy && w125 && dx && planes > 0 && T >= 1 && H >= 1 && W >= 1, "hp_laplacian5_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = planes * T * H * W;
+  HP_REQUIRE((total + 255) / 256 < (1l << 31), "hp_laplacian5_backward: too many voxels");
+  HP_PROF("laplacian5_bwd", st);
+  hipLaunchKernelGGL(k_laplacian5_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, w125, dx, T, H, W, total);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

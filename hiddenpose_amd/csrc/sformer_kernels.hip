@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <cfloat>
 
+#include <type_traits>
+
 #include "hp_internal.h"
 
 namespace hp {
@@ -298,13 +300,22 @@ __global__ __launch_bounds__(ST) void k_attention(const float* __restrict__ Q, c
 // 2 + 2 v_mfma_f32_32x32x16_bf16 instead of 16 + 16 fp32 MFMAs.  The MFMA k-slots of step t are mapped to the
 // accumulator rows the lane already holds (slot (half, j) <-> register 8t + j <-> key (j&3) + 8(2t + (j>>2)) + 4 half),
 // and the V tile is staged transposed with its keys in that slot order, so both P and V^T are one 16-byte read.
-using bf16x8s = __attribute__((ext_vector_type(8))) __bf16;
-__global__ __launch_bounds__(ST) void k_attention_patch_bf16(const float* __restrict__ Q, const float* __restrict__ K,
+// H = __bf16 (v_mfma_f32_32x32x16_bf16) or _Float16 (v_mfma_f32_32x32x16_f16: the "MFMA fp16 attention" of BASELINE
+// configs[4] to the letter; 11 significand bits instead of 8 on Q, K, V and the probabilities, same rate, same dataflow).
+template <typename H>
+__device__ __forceinline__ f32x16 mfma_h16(const __attribute__((ext_vector_type(8))) H a, const __attribute__((ext_vector_type(8))) H b,
+                                           f32x16 c) {
+  if constexpr (std::is_same<H, _Float16>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <typename H>
+__global__ __launch_bounds__(ST) void k_attention_patch_h16(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ V, float* __restrict__ out, int heads,
                                                              int Ntok, int nj, int n, int frames) {
   constexpr int DH = 32, LDB = DH + 8;  // 80-byte rows: the 16-byte fragment reads of 32 rows spread over all banks
-  __shared__ __attribute__((aligned(16))) __bf16 Kh[32 * LDB];   // [key][d]
-  __shared__ __attribute__((aligned(16))) __bf16 Vt[32 * LDB];   // [d][key slot]
+  using bf16x8s = __attribute__((ext_vector_type(8))) H;
+  __shared__ __attribute__((aligned(16))) H Kh[32 * LDB];   // [key][d]
+  __shared__ __attribute__((aligned(16))) H Vt[32 * LDB];   // [d][key slot]
   __shared__ float os[4][32 * (DH + 1)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, half = lane >> 5;
   const int bh = blockIdx.y / frames, f = blockIdx.y % frames;
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(ST) void k_attention_patch_bf16(const float* __rest
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[s2][j] = (__bf16)(qvalid ? Qb[(long)qtok * DH + 16 * s2 + 8 * half + j] : 0.f);
+    for (int j = 0; j < 8; ++j) qf[s2][j] = (H)(qvalid ? Qb[(long)qtok * DH + 16 * s2 + 8 * half + j] : 0.f);
 
   f32x16 oacc;
 #pragma unroll
@@ -339,16 +350,16 @@ __global__ __launch_bounds__(ST) void k_attention_patch_bf16(const float* __rest
         kv = *(const float4*)(Kb + (long)tok * DH + d);
         vv = *(const float4*)(Vb + (long)tok * DH + d);
       }
-      __bf16* kd = Kh + kr * LDB + d;
-      kd[0] = (__bf16)kv.x;
-      kd[1] = (__bf16)kv.y;
-      kd[2] = (__bf16)kv.z;
-      kd[3] = (__bf16)kv.w;
+      H* kd = Kh + kr * LDB + d;
+      kd[0] = (H)kv.x;
+      kd[1] = (H)kv.y;
+      kd[2] = (H)kv.z;
+      kd[3] = (H)kv.w;
       const int slot = (kr >> 4) * 16 + ((kr >> 2) & 1) * 8 + (kr & 3) + 4 * ((kr >> 3) & 1);
-      Vt[(d + 0) * LDB + slot] = (__bf16)vv.x;
-      Vt[(d + 1) * LDB + slot] = (__bf16)vv.y;
-      Vt[(d + 2) * LDB + slot] = (__bf16)vv.z;
-      Vt[(d + 3) * LDB + slot] = (__bf16)vv.w;
+      Vt[(d + 0) * LDB + slot] = (H)vv.x;
+      Vt[(d + 1) * LDB + slot] = (H)vv.y;
+      Vt[(d + 2) * LDB + slot] = (H)vv.z;
+      Vt[(d + 3) * LDB + slot] = (H)vv.w;
     }
     __syncthreads();
     f32x16 sacc;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(ST) void k_attention_patch_bf16(const float* __rest
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8s*)(Kh + col * LDB + 16 * s2 + 8 * half), qf[s2], sacc, 0, 0, 0);
+      sacc = mfma_h16<H>(*(const bf16x8s*)(Kh + col * LDB + 16 * s2 + 8 * half), qf[s2], sacc);
     float tm = -FLT_MAX;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -383,8 +394,8 @@ __global__ __launch_bounds__(ST) void k_attention_patch_bf16(const float* __rest
     for (int t = 0; t < 2; ++t) {
       bf16x8s pf;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[8 * t + j];
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8s*)(Vt + col * LDB + 16 * t + 8 * half), pf, oacc, 0, 0, 0);
+      for (int j = 0; j < 8; ++j) pf[j] = (H)sacc[8 * t + j];
+      oacc = mfma_h16<H>(*(const bf16x8s*)(Vt + col * LDB + 16 * t + 8 * half), pf, oacc);
     }
   }
   // normalise, transpose through LDS and store 128-byte rows
@@ -495,8 +506,9 @@ extern "C" int hp_sformer_attention(const float* Q, const float* K, const float*
                                     void* workspace, void* stream) {
   HP_REQUIRE(Q && K && K0 && V && out && workspace, "hp_sformer_attention: null argument");
   HP_REQUIRE(num_joints <= 32 && Ntok == num_joints + frames * patches_per_frame, "hp_sformer_attention: bad token layout");
-  HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_sformer_attention: precision %d not built",
-             precision);
+  HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16 || precision == HP_PRECISION_FP16,
+             "hp_sformer_attention: precision %d not built", precision);
+  HP_REQUIRE(precision == HP_PRECISION_FP32 || dh == 32, "hp_sformer_attention: the 16-bit patch attention is built for dim_head 32");
   if (dh != 16 && dh != 24 && dh != 32) {
     set_error("hp_sformer_attention: dim_head %d not built (16, 24, 32)", dh);
     return HP_ERR_UNSUPPORTED;
@@ -509,7 +521,10 @@ extern "C" int hp_sformer_attention(const float* Q, const float* K, const float*
   {
     HP_PROF("sformer_attention_patch", st);
     if (dh == 32 && precision == HP_PRECISION_BF16)
-      hipLaunchKernelGGL(k_attention_patch_bf16, gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame,
+      hipLaunchKernelGGL(k_attention_patch_h16<__bf16>, gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame,
+                         frames);
+    else if (dh == 32 && precision == HP_PRECISION_FP16)
+      hipLaunchKernelGGL(k_attention_patch_h16<_Float16>, gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame,
                          frames);
     else if (dh == 32) hipLaunchKernelGGL((k_attention<32>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);
     else if (dh == 24) hipLaunchKernelGGL((k_attention<24>), gp, dim3(ST), 0, st, Q, K, V, out, heads, Ntok, num_joints, patches_per_frame, frames, 0, part);

@@ -78,6 +78,11 @@ class GradBucketReducer:
                 o += p.numel()
                 self._bucket_of[p] = bi
             self.flat.append(flat)
+        # persistent staging per bucket (allocated on first use, on the communication stream, and kept): the wire image
+        # of the bucket, the owned shard and -- for "a2a" -- the receive buffer.  Nothing is allocated per step.
+        self._wire: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._shard: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._recv: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._pending = [0] * len(self.buckets)
         self._arrived = set()
         self._hooks = []
@@ -117,19 +122,30 @@ class GradBucketReducer:
         self._side = side_stream
         self._on_grad(p)
 
-    def _exchange(self, flat: torch.Tensor) -> None:
-        """Average `flat` over the group, in place; runs on the current (communication) stream."""
+    def _exchange(self, bi: int) -> None:
+        """Average bucket `bi` over the group, in place; runs on the current (communication) stream.  The staging
+        buffers are only ever touched on that stream, bucket by bucket in launch order, so they can be reused every step."""
+        flat = self.flat[bi]
         flat.div_(self.world)
-        buf = flat.to(self.wire_dtype) if (self.wire_dtype is not None and self.wire_dtype != flat.dtype) else flat
+        buf = flat
+        if self.wire_dtype is not None and self.wire_dtype != flat.dtype:
+            if self._wire[bi] is None:
+                self._wire[bi] = torch.empty(flat.numel(), dtype=self.wire_dtype, device=flat.device)
+            buf = self._wire[bi]
+            buf.copy_(flat)
         if self.algo == "all_reduce":
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         else:
             w = self.world
-            shard = torch.empty(buf.numel() // w, dtype=buf.dtype, device=buf.device)
+            if self._shard[bi] is None:
+                self._shard[bi] = torch.empty(buf.numel() // w, dtype=buf.dtype, device=buf.device)
+            shard = self._shard[bi]
             if self.algo == "rs_ag":
                 dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
             else:
-                recv = torch.empty_like(buf)
+                if self._recv[bi] is None:
+                    self._recv[bi] = torch.empty_like(buf)
+                recv = self._recv[bi]
                 dist.all_to_all_single(recv, buf, group=self.group)
                 torch.sum(recv.view(w, -1), dim=0, out=shard)
             dist.all_gather_into_tensor(buf, shard, group=self.group)
@@ -139,14 +155,14 @@ class GradBucketReducer:
     def _launch(self, bi: int) -> None:
         flat = self.flat[bi]
         if self._comm_stream is None:
-            self._exchange(flat)
+            self._exchange(bi)
             return
         cs = self._comm_stream
         cs.wait_stream(torch.cuda.current_stream(flat.device))
         if self._side is not None:
             cs.wait_stream(self._side)
         with torch.cuda.stream(cs):
-            self._exchange(flat)
+            self._exchange(bi)
 
     def finish(self) -> None:
         """Wait for every bucket (buckets whose parameters got no gradient this step are

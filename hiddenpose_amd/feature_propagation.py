@@ -10,7 +10,11 @@ Differences from the reference, on purpose:
   * any batch size (the reference indexes 3-element time_begin/time_end lists, B <= 3);
   * constants live on the device of the input tensor (the reference hard-codes 'cuda');
   * partial time windows (tbe, ten) -- NlosPose itself only issues tbe = 0, ten = T (models/NlosPose.py:53) --
-    are placed on the zero time axis by hp_lct_time_window before the transform.
+    are placed on the zero time axis by hp_lct_time_window before the transform;
+  * mode 'bp' (back-projection: inverse filter conj(F) without the Wiener denominator, then the 5^3 Laplacian-of-Gaussian
+    filter over a replication-padded volume and a zeroed first time slice, :93-94, :103-107, :246-253) is built.  In the
+    reference this file asserts mode == 'lct' and its 'bp' branch calls a filterLaplacian it never imports; the twin
+    models/tflct.py (same code, imports utils/helper.py:13-32) runs that branch and is what the goldens come from.
 """
 from __future__ import annotations
 
@@ -24,13 +28,30 @@ from torch import nn
 from . import _lib
 
 _MATERIAL = {"diffuse": 0, "specular": 1}
+_MODE = {"lct": 0, "bp": 1}
+
+
+def filter_laplacian() -> np.ndarray:
+    """utils/helper.py:13-32: 5x5x5 Laplacian of a Gaussian (std 1) in float32, mean removed.  Host constants, built
+    with the reference's float32 NumPy expression order so that the 125 weights are bit-identical."""
+    lim = 2
+    d = np.arange(-lim, lim + 1, dtype=np.float32)
+    y, x, z = np.meshgrid(d, d, d)
+    r2 = x ** 2 + y ** 2 + z ** 2
+    std2 = 1.0
+    w = np.exp(-r2 / (2 * std2))
+    w = w / np.sum(w)
+    w1 = w * (r2 - 3 * std2)
+    w1 = w1 / (std2 ** 2)
+    return w1 - np.mean(w1)
 
 
 class LCTPlan:
     """Owner of one hp_lct_plan (device constants: inverse PSF spectrum, band tables,
     twiddles).  Replaces LCT._parpareparam + todev (feature_propagation.py:71-184)."""
 
-    def __init__(self, T: int, N: int, bin_len: float, wall_size: float, material: str, device: torch.device):
+    def __init__(self, T: int, N: int, bin_len: float, wall_size: float, material: str, device: torch.device,
+                 mode: str = "lct"):
         import ctypes as C
 
         self.T, self.N, self.device = T, N, torch.device(device)
@@ -38,8 +59,8 @@ class LCTPlan:
             raise _lib.HiddenPoseHipError("LCTPlan needs a HIP device (tensor on %s)" % self.device)
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _lib.check(_lib.lib().hp_lct_plan_create(C.byref(h), T, N, float(bin_len), float(wall_size),
-                                                 _MATERIAL[material], idx), "hp_lct_plan_create")
+        _lib.check(_lib.lib().hp_lct_plan_create_mode(C.byref(h), T, N, float(bin_len), float(wall_size),
+                                                      _MATERIAL[material], _MODE[mode], idx), "hp_lct_plan_create_mode")
         self.handle = h
         self._finalizer = weakref.finalize(self, _lib.lib().hp_lct_plan_destroy, h)
 
@@ -78,6 +99,32 @@ class _LCTFunction(torch.autograd.Function):
         return ctx.plan.run(gy.contiguous(), backward=True), None
 
 
+class _Laplacian5(torch.autograd.Function):
+    """'bp' epilogue (:246-253): ReplicationPad3d(2) -> conv3d(5^3 LoG) -> [:, :1] = 0 on (planes, T, H, W)."""
+
+    @staticmethod
+    def forward(ctx, v, w125):
+        v = v.contiguous()
+        p, t, h, w = v.shape
+        y = torch.empty_like(v)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().hp_laplacian5_forward(v.data_ptr(), w125.data_ptr(), y.data_ptr(), p, t, h, w,
+                                                        _lib.current_stream_handle(v.device)), "hp_laplacian5_forward")
+        ctx.save_for_backward(w125)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (w125,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        p, t, h, w = gy.shape
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            _lib.check(_lib.lib().hp_laplacian5_backward(gy.data_ptr(), w125.data_ptr(), gx.data_ptr(), p, t, h, w,
+                                                         _lib.current_stream_handle(gy.device)), "hp_laplacian5_backward")
+        return gx, None
+
+
 class _TimeWindow(torch.autograd.Function):
     """models/feature_propagation.py:193-200: equal-length samples at per-sample offsets of a zero time axis."""
 
@@ -108,17 +155,18 @@ class _TimeWindow(torch.autograd.Function):
 
 
 class LCT(nn.Module):
-    """models/feature_propagation.py:46-257 (mode 'lct')."""
+    """models/feature_propagation.py:46-257 (modes 'lct' and 'bp')."""
 
     def __init__(self, image_size=256, time_size=128, bin_len=0.01, wall_size=2.0, mode="lct", material="diffuse"):
         super().__init__()
-        assert mode == "lct", f"{mode} is not spported. Feature propagation only support lct by now"
+        assert mode in _MODE, f"{mode} is not spported. Feature propagation supports lct and bp"
         assert 2 ** int(np.log2(time_size)) == time_size, "time size should be a power of 2"
         assert material in _MATERIAL
         _lib.lib()  # the HIP extension is mandatory
         self.image_size, self.time_size = int(image_size), int(time_size)
         self.bin_len, self.wall_size, self.mode, self.material = bin_len, wall_size, mode, material
         self._plans = {}
+        self._lapw = {}
         self._plock = threading.Lock()
 
     def todev(self, dev, dnum=1):
@@ -136,8 +184,10 @@ class LCT(nn.Module):
         with self._plock:
             p = self._plans.get(device)
             if p is None:
-                p = LCTPlan(self.time_size, self.image_size, self.bin_len, self.wall_size, self.material, device)
+                p = LCTPlan(self.time_size, self.image_size, self.bin_len, self.wall_size, self.material, device, self.mode)
                 self._plans[device] = p
+                if self.mode == "bp":
+                    self._lapw[device] = torch.from_numpy(filter_laplacian().astype(np.float32)).reshape(-1).to(device)
         return p
 
     def forward(self, feture_bxdxtxhxw, tbes=None, tens=None):
@@ -154,7 +204,10 @@ class LCT(nn.Module):
                 x = _TimeWindow.apply(x.float(), list(tbes[:b]), self.time_size)
                 t = self.time_size
         assert t == self.time_size and h == w == self.image_size
-        y = _LCTFunction.apply(x.reshape(b * d, t, h, w).float(), self.plan_for(x.device))
+        plan = self.plan_for(x.device)
+        y = _LCTFunction.apply(x.reshape(b * d, t, h, w).float(), plan)
+        if self.mode == "bp":
+            y = _Laplacian5.apply(y, self._lapw[plan.device])
         return y.view(b, d, t, h, w)
 
 
@@ -164,7 +217,7 @@ class FeaturePropagation(nn.Module):
     def __init__(self, image_size=256, time_size=512, bin_len=0.01, wall_size=2.0, mode="lct", material="diffuse",
                  dnum=1, dev="cpu"):
         super().__init__()
-        assert mode == "lct", f"{mode} is not spported. Feature propagation only support lct by now"
+        assert mode in _MODE, f"{mode} is not spported. Feature propagation supports lct and bp"
         self.method = LCT(int(image_size), time_size, bin_len, wall_size, mode=mode, material=material)
 
     def forward(self, x, time_begin=None, time_end=None):

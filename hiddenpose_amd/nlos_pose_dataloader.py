@@ -24,7 +24,8 @@ FRAMES, KEEP_FRAMES = 600, 512  # rearrange '(t h) w -> t h w', t=600 and [:512]
 
 def decode_hdr(path: str, pinned=None):
     """Radiance file -> (rows, W, 4) uint8 RGBE on the host (file parsing only; hp_rgbe_decode).  `pinned`: a callable
-    nbytes -> page-locked uint8 torch tensor to decode into (the result is then a view of it, a torch tensor)."""
+    nbytes -> page-locked uint8 torch tensor to decode into (the result is then a view of it, a torch tensor).
+    The first call is the size query: it parses the text header only and returns before the run-length stream."""
     L = _lib.lib()
     raw = np.fromfile(path, dtype=np.uint8)
     w, h = C.c_int(0), C.c_int(0)
@@ -109,44 +110,55 @@ class NlosPoseDataset(Dataset):
             print(f"total {self.phase} {kind} is {len(files)}")
 
     # ---- host half (file I/O + run-length expansion; runs in worker threads of PrefetchingLoader) ----------------
+    def wrong_meas(self, index):
+        """:76-81, :96-104: report a measurement that cannot be used; the caller substitutes sample 0."""
+        meas_file = self.measFiles[index]
+        print(f"--------------------\nNo.{index} {meas_file} meas is wrong. \n--------------------------\n")
+        self.wrongMeasFiles.append(meas_file)
+
     def load_host(self, index, pinned=None):
         """Everything of sample `index` that needs no GPU: the expanded RGBE image (uint8, pinned if `pinned` hands a
-        reusable page-locked buffer), the raw volume, the remapped joints.  Raises on an unreadable measurement."""
+        reusable page-locked buffer), the raw volume, the remapped joints.  As in the reference (:72-104) only the
+        MEASUREMENT is guarded: a file that cannot be decoded is replaced by sample 0's measurement and joints while the
+        volume stays the failing sample's; an unreadable .mat / .joints file raises (loadmat / loadtxt at :108-109 are
+        outside the reference's try block)."""
         from scipy.io import loadmat
 
-        meas_file, joint_file = self.measFiles[index], self.jointsFiles[index]
-        rgbe = decode_hdr(meas_file, pinned)
+        meas_index = index
+        try:
+            rgbe = decode_hdr(self.measFiles[index], pinned)
+        except Exception:
+            self.wrong_meas(index)
+            meas_index = 0
+            rgbe = decode_hdr(self.measFiles[0], pinned)
+        meas_file, joint_file = self.measFiles[meas_index], self.jointsFiles[meas_index]
         vol = loadmat(self.volFiles[index])["vol"].astype(np.float32)
         joints = remap_joints(np.loadtxt(joint_file), self.vol_size[0], self.heatmap_size[0])
-        return {"rgbe": rgbe, "vol": vol, "joints": joints, "id": os.path.splitext(os.path.basename(meas_file))[0]}
+        return {"rgbe": rgbe, "vol": vol, "joints": joints, "id": os.path.splitext(os.path.basename(meas_file))[0],
+                "index": index}
 
     # ---- device half (decode, normalisations, gray, crop, pyramids; on the CURRENT stream) ---------------------------
+    def meas_to_device(self, rgbe: torch.Tensor, index: int = 0) -> torch.Tensor:
+        """Expanded RGBE image (device, uint8) -> network measurement (:74-83, :107-117).  Raises ValueError on an
+        all-zero image (:75).  Subclasses (the noise dataset) replace this stage."""
+        return rgbe_to_meas(rgbe, self.downsample_cnt)
+
     def to_device(self, host):
         rgbe = host["rgbe"] if torch.is_tensor(host["rgbe"]) else torch.from_numpy(host["rgbe"])
-        meas = rgbe_to_meas(rgbe.to(self.device, non_blocking=True), self.downsample_cnt)
+        meas = self.meas_to_device(rgbe.to(self.device, non_blocking=True), host.get("index", 0))
         vol = box_pyramid(torch.from_numpy(host["vol"]).to(self.device, non_blocking=True), self.downsample_cnt)
         return meas[None], vol[None]
 
-    def _meas(self, path):
-        rgbe = torch.from_numpy(decode_hdr(path)).to(self.device, non_blocking=True)
-        return rgbe_to_meas(rgbe, self.downsample_cnt)
-
     def __getitem__(self, index):
-        from scipy.io import loadmat
-
-        meas_file, joint_file = self.measFiles[index], self.jointsFiles[index]
+        host = self.load_host(index)
         try:
-            meas = self._meas(meas_file)
-        except Exception:  # :84-104: any failure falls back to sample 0 (meas and joints, not the volume)
-            print(f"--------------------\nNo.{index} {meas_file} meas is wrong. \n--------------------------\n")
-            self.wrongMeasFiles.append(meas_file)
-            meas_file, joint_file = self.measFiles[0], self.jointsFiles[0]
-            meas = self._meas(meas_file)
-        vol = torch.from_numpy(loadmat(self.volFiles[index])["vol"].astype(np.float32)).to(self.device)
-        vol = box_pyramid(vol, self.downsample_cnt)
-        joints = remap_joints(np.loadtxt(joint_file), self.vol_size[0], self.heatmap_size[0])
-        person_id = os.path.splitext(os.path.basename(meas_file))[0]
-        return meas[None], vol[None], joints, person_id
+            meas, vol = self.to_device(host)
+        except ValueError:   # :75-81: an all-zero measurement -> sample 0's measurement and joints, this sample's volume
+            self.wrong_meas(index)
+            h0 = self.load_host(0)
+            host = dict(h0, vol=host["vol"], index=index)
+            meas, vol = self.to_device(host)
+        return meas, vol, host["joints"], host["id"]
 
     def __len__(self):
         return len(self.volFiles)
@@ -218,19 +230,7 @@ class PrefetchingLoader:
         stop = threading.Event()
 
         def host(i):
-            try:
-                return ds.load_host(i, self._pinned)
-            except Exception:
-                print(f"--------------------\nNo.{i} {ds.measFiles[i]} meas is wrong. \n--------------------------\n")
-                ds.wrongMeasFiles.append(ds.measFiles[i])
-                h0 = ds.load_host(0, self._pinned)
-                try:   # the reference keeps the failing sample's volume
-                    from scipy.io import loadmat
-
-                    h0["vol"] = loadmat(ds.volFiles[i])["vol"].astype(np.float32)
-                except Exception:
-                    pass
-                return h0
+            return ds.load_host(i, self._pinned)   # guards the measurement decode only; .mat / .joints errors surface
 
         def device_stage():
             side = torch.cuda.Stream(dev)
@@ -251,11 +251,11 @@ class PrefetchingLoader:
                         for k, h in enumerate(items):
                             try:
                                 m, v = ds.to_device(h)
-                            except ValueError:   # all-zero measurement (:75): sample 0 instead
+                            except ValueError:   # all-zero measurement (:75): sample 0's measurement and joints instead
+                                ds.wrong_meas(h["index"])
                                 h0 = host(0)
-                                m, _ = ds.to_device(h0)
-                                _, v = ds.to_device({"rgbe": h0["rgbe"], "vol": h["vol"]})
-                                items[k] = dict(h0, vol=h["vol"])
+                                items[k] = dict(h0, vol=h["vol"], index=h["index"])
+                                m, v = ds.to_device(items[k])
                             ms.append(m)
                             vs.append(v)
                         meas, vol = torch.stack(ms), torch.stack(vs)

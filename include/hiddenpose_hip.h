@@ -71,7 +71,19 @@ int hp_lct_host_constants(int T, int N, double bin_len, double wall_size,
 /* Builds all constants on the host, uploads them to `device` (HIP ordinal). */
 int hp_lct_plan_create(hp_lct_plan** plan, int T, int N, double bin_len, double wall_size,
                        int material, int device);
+/* The same with the inverse filter of the reference's 'bp' mode (models/feature_propagation.py:93-94, models/tflct.py:59-60):
+ * invpsf = conj(fftn(psf)) instead of the Wiener filter conj(F) / (1/snr + |F|^2).  The Laplacian-of-Gaussian epilogue of
+ * that mode is hp_laplacian5_*. */
+#define HP_LCT_MODE_LCT 0
+#define HP_LCT_MODE_BP 1
+int hp_lct_plan_create_mode(hp_lct_plan** plan, int T, int N, double bin_len, double wall_size,
+                            int material, int mode, int device);
 int hp_lct_plan_destroy(hp_lct_plan* plan);
+/* Epilogue of the 'bp' mode (models/feature_propagation.py:246-253; models/tflct.py:164-174): per (planes) volume
+ * (T, H, W): ReplicationPad3d(2) -> conv3d with the 5x5x5 Laplacian-of-Gaussian filter w125 (device pointer, [kt][kh][kw];
+ * utils/helper.py:13-32 builds it) -> first time slice set to 0.  _backward is the adjoint (gradient w.r.t. x). */
+int hp_laplacian5_forward(const float* x, const float* w125, float* y, long planes, int T, int H, int W, void* stream);
+int hp_laplacian5_backward(const float* dy, const float* w125, float* dx, long planes, int T, int H, int W, void* stream);
 /* Bytes of caller-provided scratch needed for a batch of B volumes (B*D in
  * the reference's naming). */
 size_t hp_lct_workspace_bytes(const hp_lct_plan* plan, int batch);
@@ -118,6 +130,7 @@ int hp_lct_plan_get_invpsf(const hp_lct_plan* plan, float* invpsf_re, float* inv
 #define HP_PRECISION_BF16 1
 #define HP_PRECISION_BF16X3 2
 #define HP_PRECISION_BF16X6 3
+#define HP_PRECISION_FP16 4 /* hp_sformer_attention only: fp16 operands (v_mfma_f32_32x32x16_f16), fp32 soft-max / accumulation */
 typedef struct hp_conv_desc {
   int B, Di, Hi, Wi; /* input volume */
   int Cin, Cout;
@@ -373,8 +386,9 @@ int hp_sformer_qkv_prepare(const float* qkv, float* Q, float* K, float* K0, floa
 /* spatial attention with joint tokens (:284-319): joint queries attend to all tokens, patch queries to
  * [joint tokens | patches of their frame]; out (B, Ntok, heads*dh) with heads merged. */
 size_t hp_sformer_attention_workspace_bytes(int B, int heads, int dh);
-/* precision: HP_PRECISION_FP32 (exact-fp32 MFMA) or HP_PRECISION_BF16 (patch-token attention with bf16 operands on
- * the bf16 matrix cores, fp32 soft-max and accumulation, dim_head 32; the 24 joint queries stay fp32). */
+/* precision: HP_PRECISION_FP32 (exact-fp32 MFMA), HP_PRECISION_BF16 or HP_PRECISION_FP16 (patch-token attention with
+ * bf16 / fp16 operands on the 16-bit matrix cores, fp32 soft-max and accumulation, dim_head 32; the 24 joint queries stay
+ * fp32).  HP_PRECISION_FP16 is BASELINE configs[4]'s "MFMA fp16 attention" (models/NlosPoseSformer.py:284-319). */
 int hp_sformer_attention(const float* Q, const float* K, const float* K0, const float* V, float* out, int B, int heads,
                          int dh, int Ntok, int num_joints, int patches_per_frame, int frames, int precision,
                          void* workspace, void* stream);
@@ -398,6 +412,18 @@ int hp_rgbe_decode(const unsigned char* file, size_t nbytes, int* width, int* he
  * 'abs(meas.max()) < 1e-10 -> wrong Meas File' rule at :75). */
 int hp_ingest_rgbe_to_meas(const unsigned char* rgbe, int frames, int H, int W, int keep_frames, int downsample_cnt,
                            float* meas, float* maxima, void* stream);
+/* Noise variant of the ingest (utils/nlos_pose_dataloader_noise.py:86-118: gray of the RAW image -- its first "/ max" is
+ * commented out at :92 --, addnoise_dataset, "/ max" of the noisy image, then the same crop and pyramid):
+ *   hp_ingest_rgbe_to_gray   RGBE bytes -> gray[npx] = (0.114 B + 0.587 G) + 0.299 R of the decoded floats; maxima[0] = the
+ *                            largest decoded channel value (the :88 'wrong Meas File' test)
+ *   hp_noise_blur_poisson    addnoise_dataset on the flattened gray image (declared above)
+ *   hp_ingest_image_to_meas  image / max(image) -> '(t h) w -> t h w'[:keep_frames] -> time pairs -> box rounds, as
+ *                            hp_ingest_rgbe_to_meas does from the bytes.  float64 != 0: divide and average in double and
+ *                            round once at the end (NumPy on the int64 Poisson counts); 0: float32 throughout (a float32
+ *                            image, e.g. blur only).  maxima[0] receives the image maximum. */
+int hp_ingest_rgbe_to_gray(const unsigned char* rgbe, long npx, float* gray, float* maxima, void* stream);
+int hp_ingest_image_to_meas(const float* image, int frames, int H, int W, int keep_frames, int downsample_cnt, int float64,
+                            float* meas, float* maxima, void* stream);
 /* One round of the reference's box pyramid on a float volume addressed by element strides:
  * out[d,h,w] = pair averages along d, then h, then w (each (a+b)/2), contiguous (D/2, H/2, W/2)  (:114-121) */
 int hp_box_downsample_round(const float* in, float* out, int D, int H, int W, long stride_d, long stride_h,

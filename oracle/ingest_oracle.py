@@ -114,6 +114,40 @@ def meas_from_bgr(bgr: np.ndarray, frames: int = 600, keep: int = 512, downsampl
     return meas.astype(np.float32)
 
 
+def addnoise_dataset(meas: np.ndarray, rng=None, sigma: float = 10.61) -> np.ndarray:
+    """utils/nlos_pose_dataloader_noise.py:167-172: 'a b -> (a b)', cv2.GaussianBlur(ksize=(0, 0), sigmaX=10.61,
+    BORDER_REPLICATE) along that one long column, numpy.random.poisson of the result.  `rng` = a numpy Generator /
+    RandomState for the Poisson draw, None = stop after the blur (float32, deterministic).  Returned in the (a, b) shape
+    (the reference hands back cv2's (a*b, 1) column and then folds it at :106 as if it were (a, b): see the note in
+    hiddenpose_amd/nlos_pose_dataloader_noise.py)."""
+    try:
+        from nlospose_oracle import blur_flat_replicate
+    except ImportError:  # imported as a package member
+        from oracle.nlospose_oracle import blur_flat_replicate
+    blurred = blur_flat_replicate(meas, sigma)
+    if rng is None:
+        return blurred
+    return rng.poisson(blurred.astype(np.float64))   # int64, as numpy.random.poisson returns
+
+
+def meas_from_bgr_noise(bgr: np.ndarray, rng=None, frames: int = 600, keep: int = 512, downsample_cnt: int = 1,
+                        sigma: float = 10.61) -> np.ndarray:
+    """utils/nlos_pose_dataloader_noise.py:86-94, :106, :112-117 given what cv2.imread returned: gray of the RAW image
+    (the first '/ max' is commented out at :92), addnoise_dataset, '/ max' (float64 when the image holds int64 Poisson
+    counts, float32 for the blur-only image), crop, time pairs, box rounds."""
+    meas = bgr
+    if abs(meas.max()) < 1e-10:
+        raise ValueError("wrong Meas File!")
+    meas = bgr2gray_f32(meas)
+    meas = addnoise_dataset(meas, rng, sigma)
+    meas = meas / np.max(meas)
+    meas = meas.reshape(frames, -1, meas.shape[-1])[:keep]
+    meas = (meas[::2] + meas[1::2]) / 2
+    for _ in range(downsample_cnt):
+        meas = box_round(meas)
+    return meas.astype(np.float32)
+
+
 def meas_from_hdr(buf: bytes, frames: int = 600, keep: int = 512, downsample_cnt: int = 1) -> np.ndarray:
     return meas_from_bgr(rgbe_to_bgr_float(rgbe_read(buf)), frames, keep, downsample_cnt)
 

@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: lctwin ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax specular e2e128train highres
+Sections: lctwin ingest sformer schema consts lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train highres
 (default: all; highres needs ~45 GB of RAM and ~15 minutes)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
@@ -305,6 +305,29 @@ def sec_specular():
     (y * gy).sum().backward()
     save("lct_specular.npz", y=y.detach().numpy(), gx=x.grad.numpy())
     print(f"  specular: |y| {y.norm().item():.4g} |gx| {x.grad.norm().item():.4g}")
+
+
+def sec_bp():
+    """mode 'bp' (models/feature_propagation.py:93-94,103-107,246-253) from the reference's runnable twin models/tflct.py
+    (method='bp': conj-only inverse filter, ReplicationPad3d(2) + 5^3 Laplacian of Gaussian from utils/helper.py:13-32,
+    first time slice zeroed).  tflct.lct fixes its time size at 128 whatever `crop` says (:19), so T = 128, N = 16.
+    Forward + input gradient, and the 125 filter weights themselves."""
+    import models.tflct as tf
+    from utils.helper import filterLaplacian
+
+    T, N, B = 128, 16, 2
+    lct = tf.lct(spatial=N, crop=T, bin_len=0.04, wall_size=2.0, method="bp")
+    lct.todev("cpu", 1)
+    x = hpt.synthetic_meas(B, T, N, "uniform", seed=0).requires_grad_(True)
+    y = lct(x, [0] * B, [T] * B)
+    gy = hpt.synthetic_meas(B, T, N, "uniform", seed=100) - 0.5
+    (y * gy).sum().backward()
+    # the Wiener twin of the same class on the same input: pins that tflct's 'lct' branch equals feature_propagation's
+    lct_w = tf.lct(spatial=N, crop=T, bin_len=0.04, wall_size=2.0, method="lct")
+    lct_w.todev("cpu", 1)
+    yw = lct_w(x.detach(), [0] * B, [T] * B)
+    save("lct_bp.npz", y=y.detach().numpy(), gx=x.grad.numpy(), lapw=filterLaplacian().astype(np.float32), y_lct=yw.numpy())
+    print(f"  bp: |y| {y.norm().item():.4g} |gx| {x.grad.norm().item():.4g} |y_lct| {yw.norm().item():.4g}")
 
 
 def sec_visible():
@@ -690,7 +713,7 @@ def sec_ingest():
 
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
-            "specular": sec_specular, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "highres": sec_highres}
+            "specular": sec_specular, "bp": sec_bp, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "highres": sec_highres}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

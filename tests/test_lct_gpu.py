@@ -112,6 +112,52 @@ def test_specular_material_vs_reference_golden(golden):
     assert rel_l2(y.detach().cpu().numpy(), golden("lct_io.npz")["small_y"]) > 1e-2
 
 
+def test_bp_mode_vs_reference_golden(golden):
+    """mode 'bp' (models/feature_propagation.py:93-94,103-107,246-253; golden from models/tflct.py method='bp'): the
+    conj-only inverse filter inside the five LCT passes, then hp_laplacian5_forward; backward = hp_laplacian5_backward
+    (adjoint of pad + filter + zeroed slice) followed by the LCT adjoint.  Forward, input gradient, adjoint identity."""
+    from hiddenpose_amd.feature_propagation import FeaturePropagation, filter_laplacian
+
+    g = golden("lct_bp.npz")
+    assert np.array_equal(filter_laplacian().astype(np.float32), g["lapw"])
+    fp = FeaturePropagation(16, 128, 0.04, 2.0, mode="bp")
+    x = hpt.synthetic_meas(2, 128, 16, "uniform", seed=0).cuda().requires_grad_(True)
+    y = fp(x, [0, 0], [128, 128])
+    gy = (hpt.synthetic_meas(2, 128, 16, "uniform", seed=100) - 0.5).cuda()
+    (y * gy).sum().backward()
+    assert rel_l2(y.detach().cpu().numpy(), g["y"]) < 1e-5
+    assert rel_l2(x.grad.cpu().numpy(), g["gx"]) < 1e-5
+    assert float(y[:, :, 0].abs().max()) == 0.0
+    assert rel_l2(y.detach().cpu().numpy(), g["y_lct"]) > 1e-1      # not the Wiener operator
+    # <A x, g> == <x, A^T g> in float64 accumulation
+    lhs = float((y.detach().double() * gy.double()).sum())
+    rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs))
+
+
+@pytest.mark.gpu
+def test_laplacian5_forward_backward_vs_float64():
+    """hp_laplacian5_* alone on an anisotropic volume whose sides are not multiples of the tile: replication padding,
+    the 125 taps, the zeroed slice and the adjoint (every border / corner case of the fold) against torch in float64."""
+    import torch.nn.functional as F
+
+    from hiddenpose_amd.feature_propagation import _Laplacian5, filter_laplacian
+
+    w = torch.from_numpy(filter_laplacian().astype(np.float32))
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 9, 13, 37, generator=gen)
+    gy = torch.randn(3, 9, 13, 37, generator=gen)
+    xd = x.double().requires_grad_(True)
+    v = F.conv3d(F.pad(xd.unsqueeze(1), (2, 2, 2, 2, 2, 2), mode="replicate"), w.double().view(1, 1, 5, 5, 5)).squeeze(1)
+    ref = torch.cat([torch.zeros_like(v[:, :1]), v[:, 1:]], 1)
+    (ref * gy.double()).sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    y = _Laplacian5.apply(xc, w.reshape(-1).cuda())
+    (y * gy.cuda()).sum().backward()
+    assert rel_l2(y.detach().cpu().double().numpy(), ref.detach().numpy()) < 2e-6
+    assert rel_l2(xc.grad.cpu().double().numpy(), xd.grad.numpy()) < 2e-6
+
+
 def test_time_windows_vs_reference_golden(golden):
     """LCT.forward(x, tbes, tens) with partial windows (models/feature_propagation.py:193-200), forward and the
     gradient that flows back into the window."""

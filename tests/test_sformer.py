@@ -95,6 +95,45 @@ def test_hip_bf16_attention_config5_shape_vs_oracle():
     y32 = m(video.cuda())
     m.attention_precision = "bf16"
     y16 = m(video.cuda())
-    e32, e16 = rel_l2(y32, ref), rel_l2(y16, ref)
-    print(f"config-5 geometry: fp32 attention {e32:.2e}, bf16 attention {e16:.2e}")
-    assert e32 < 1e-3 and e16 < 2e-2
+    m.attention_precision = "fp16"   # BASELINE configs[4]: "MFMA fp16 attention" (v_mfma_f32_32x32x16_f16)
+    yh = m(video.cuda())
+    e32, e16, eh = rel_l2(y32, ref), rel_l2(y16, ref), rel_l2(yh, ref)
+    print(f"config-5 geometry: fp32 attention {e32:.2e}, bf16 attention {e16:.2e}, fp16 attention {eh:.2e}")
+    assert e32 < 1e-3 and e16 < 2e-2 and eh < 2e-3
+
+
+@pytest.mark.gpu
+def test_16bit_patch_attention_op_vs_float64():
+    """hp_sformer_attention alone on random Q, K, V at the config-5 token layout (batch 1): the fp32 kernel against a float64
+    evaluation of models/NlosPoseSformer.py:284-319 (patch queries attend to [24 joint tokens | their frame]), and the two
+    16-bit kernels against the same: bf16 at its 2^-9 operand rounding, fp16 (11-bit significands) about 8 x tighter."""
+    import ctypes as C  # noqa: F401
+
+    from hiddenpose_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    B, heads, dh, nj, n, f = 1, 8, 32, 24, 1024, 2
+    ntok = nj + f * n
+    q = torch.randn(B, heads, ntok, dh, generator=g) * dh ** -0.5
+    k = torch.randn(B, heads, ntok, dh, generator=g)
+    v = torch.randn(B, heads, ntok, dh, generator=g)
+    qd, kd, vd = q.double(), k.double(), v.double()
+    ref = torch.empty(B, ntok, heads * dh, dtype=torch.float64)
+    for fr in range(f):
+        keys = torch.cat([torch.arange(nj), nj + fr * n + torch.arange(n)])
+        qs = slice(nj + fr * n, nj + (fr + 1) * n)
+        a = torch.softmax(qd[:, :, qs] @ kd[:, :, keys].transpose(-1, -2), dim=-1) @ vd[:, :, keys]
+        ref[:, qs] = a.permute(0, 2, 1, 3).reshape(B, n, heads * dh)
+    dev = torch.device("cuda", 0)
+    qc, kc, vc = q.to(dev), k.to(dev), v.to(dev)
+    st = _lib.current_stream_handle(dev)
+    ws = torch.empty(int(L.hp_sformer_attention_workspace_bytes(B, heads, dh)) // 4, device=dev)
+    errs = {}
+    for name, prec in (("fp32", 0), ("bf16", 1), ("fp16", 4)):
+        out = torch.zeros(B, ntok, heads * dh, device=dev)
+        _lib.check(L.hp_sformer_attention(qc.data_ptr(), kc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), B, heads, dh,
+                                          ntok, nj, n, f, prec, ws.data_ptr(), st), "hp_sformer_attention")
+        errs[name] = rel_l2(out[:, nj:].cpu().double(), ref[:, nj:])
+    print("patch attention vs float64:", {k2: f"{v2:.2e}" for k2, v2 in errs.items()})
+    assert errs["fp32"] < 2e-6 and errs["bf16"] < 1e-2 and errs["fp16"] < 1.5e-3
+    assert errs["fp16"] < 0.3 * errs["bf16"]

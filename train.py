@@ -29,6 +29,10 @@ def _collate(batch):
 
 
 def main(argv=None):
+    # must be in the environment before the first HIP call initialises the runtime (dmabuf IPC for RCCL);
+    # seed_everything below is the first call that touches HIP (torch.cuda.is_available)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     seed_everything(410)
     args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -36,9 +40,6 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", str(args.device)))
     args.device = (0 if os.environ.get("HP_SHARE_GPU") else local) if world > 1 else args.device
     cfg = build_config(args)
-    # must be in the environment before the first HIP call initialises the runtime (dmabuf IPC for RCCL)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     torch.cuda.set_device(cfg.DEVICE)
     reducer = None
     if world > 1:
