@@ -388,3 +388,60 @@ def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
     assert abs(jl1 / jl0 - 1) < 0.25 and rel_l2(h1, h0) < 0.25 and min(cos.values()) > 0.4   # the bf16 mode's own bars
     from hiddenpose_amd import hip_ops as ops
     assert ops.get_conv_precision() == "fp32" and not ops._act_bf16
+
+
+def test_train_step_native_128_smooth_filler_gradients_to_1e3(golden, capsys):
+    """The same 128^3 / batch-2 train step with the SECOND filler (hiddenpose_amd.testing, smooth=True: the normalisation
+    layers in front of a ReLU get gain 0.5 and bias +2, so ReLU decisions sit far from rounding noise).  With the chaotic
+    amplification of the default filler gone, the reference's own float32 gradients lie 5e-5 .. 2e-3 from its float64
+    ones (golden: spread_*), and the end-to-end gradient bar can be what north_star asks for: every named gradient within
+    max(1e-3, 2 x the reference's own float32 spread for THAT parameter) of the float64 reference -- 11 of the 15 carry the
+    plain 1e-3; the stem weight (behind MaxPool3d's arg-max) and the FeatureExtraction weights (behind the LCT's
+    cancelling sums) are as far from float64 in the reference's float32 as in ours.  A wrong backward term of any stage
+    upstream of a parameter shows at O(1e-1)."""
+    g = golden("e2e_T128_N128_train_smooth.npz")
+    B, T, N = 2, 128, 128
+    cfg = make_cfg(T, N)
+    model = NlosPose(cfg)
+    hpt.fill_module(model, smooth=True)
+    model = model.cuda().train()
+    meas = hpt.synthetic_meas(B, T, N).cuda()
+    vol = hpt.synthetic_vol(B, T, N).cuda()
+    joints = hpt.synthetic_joints(B, T // 2).cuda()
+    criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+    loss, jl, vl, heat, refine = compute_loss(model, criterion, voxel_criterion, meas, vol, joints)
+    optimizer.zero_grad()
+    loss.backward()
+    assert abs(jl.item() / float(g["joint_loss"]) - 1) < TOL
+    assert abs(vl.item() / float(g["voxel_loss"]) - 1) < TOL
+    assert abs(loss.item() / float(g["loss64"]) - 1) < TOL
+    l2 = heat.detach().reshape(B, 24, -1).double().norm(dim=2).cpu().numpy()
+    assert np.abs(l2 / g["heat_l2_per_joint"] - 1).max() < TOL
+    assert rel_l2(heat.detach()[:, :, ::8, ::8, ::8], g["heat_sub"]) < TOL
+    assert rel_l2(refine.detach()[:, :, ::8, ::8, ::8], g["refine_sub"]) < TOL
+    named = dict(model.named_parameters())
+    keys = [k[4:] for k in g.files if k.startswith("gl2_")]
+    assert len(keys) == 15
+    report = {}
+    for k in keys:
+        gr = named[k].grad.detach()
+        if "gidx_" + k in g.files:
+            e = rel_l2(gr.reshape(-1)[torch.from_numpy(g["gidx_" + k]).cuda()], g["gs64_" + k])
+        else:
+            e = rel_l2(gr, g["g64_" + k])
+        report[k] = (e, float(g["spread_" + k]))
+    with capsys.disabled():
+        print("\n[128^3 B=2 train step, smooth filler] gradient rel-L2 vs float64 reference (ours / reference's own float32): " +
+              ", ".join(f"{k.split('.', 1)[1]} {a:.1e}/{b:.1e}" for k, (a, b) in report.items()))
+    tight = 0
+    for k, (e, spread) in report.items():
+        if k == "pose_net.head.features.9.bias":   # soft-max shift invariance: the exact gradient is 0
+            assert float(named[k].grad.abs().max()) < 1e-2 * float(named["pose_net.head.features.9.weight"].grad.abs().max())
+            continue
+        if k == "autoencoder.out.conv.bias":       # 2 mean(d refine): a difference of large sums; bounded against the float64 value
+            assert e < 1e-3, (k, e)
+            continue
+        bar = max(1e-3, 2.0 * spread)
+        tight += bar == 1e-3
+        assert e < bar, (k, e, spread)
+    assert tight >= 9, tight
