@@ -186,7 +186,14 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
 // linearly (lane l -> base + 16 l = 8 rows x 8 chunks), so the bank spread comes from the SOURCE side: LDS chunk c of row r
 // holds memory chunk c ^ ((r >> 1) & 7), and the fragment reads apply the same XOR (16 rows of a ds_read_b128 lane group
 // then fall on 16 distinct 16-byte slots).
-template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false>
+// BL (exact-fp32 tiles, Cin a multiple of 32): both tiles are fetched with BUFFER loads -- descriptor base = this
+// workgroup's lowest gathered address, per-thread byte offset fixed for the whole kernel, the (tap, channel tile)
+// displacement in the scalar offset -- so a K tile's eight loads need no vector address arithmetic, and rows that must
+// read zeros (padding taps, rows past M / N_out) simply carry an offset beyond the descriptor's range: the hardware
+// returns 0.  Why it matters: tools/micro/mfma_coexec.hip -- while one wave streams fp32 MFMAs, vector-ALU, vector-memory
+// and LDS-read instructions of the OTHER waves of that SIMD do not issue at all, i.e. every such instruction of the K loop
+// is paid in matrix-pipe time whichever wave executes it.
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false>
 __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, void* __restrict__ Y,
                                               double* __restrict__ stats, const void* __restrict__ addend,
@@ -221,6 +228,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   constexpr int NPL = NP > 0 ? NP : 1;
   static_assert(!XH || (NP == 1 && !STEM), "bf16-storage tiles: single bf16 plane, not the stem");
   static_assert(!GL || (XH && BN >= 64), "direct-to-LDS tiles: bf16 storage, 64 or 128 columns");
+  static_assert(!BL || (NP == 0 && !STEM), "buffer-load tiles: exact-fp32, not the stem");
   constexpr int BKT = XH ? 64 : BK;      // K extent of a tile
   constexpr int LDX = GL ? BKT : BKT + 8;  // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
   constexpr int EPL = XH ? 8 : 4;        // elements per thread, row and load
@@ -303,6 +311,29 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     wrow[i] = (long)n * g.Cin + kq * EPL;
   }
 
+  // BL: descriptors (wave-uniform) and per-thread byte offsets
+  constexpr unsigned OOB = 0x80000000u;  // = num_records: any offset from here on reads as zero
+  long rowbase = 0;   // element offset of the tile's first row: the X descriptor's base (with min_xoff)
+  unsigned xrow32[4] = {0u, 0u, 0u, 0u}, xvoff[4] = {OOB, OOB, OOB, OOB}, wvoff[BN / 32];
+  long min_xoff = 0;  // smallest tap displacement of this class (elements): the scalar offsets are taken relative to it
+  if constexpr (BL) {
+    for (int t = 0; t < ntaps; ++t) {
+      int dz, dy, dx, widx;
+      tap_info(g, cls, t, dz, dy, dx, widx);
+      const long xo = (((long)dz * g.Hi + dy) * g.Wi + dx) * g.Cin;
+      min_xoff = (t == 0 || xo < min_xoff) ? xo : min_xoff;
+    }
+    // the tile's rows ascend with m, so its first row has the lowest base address
+    int b0, z0, y0, x0;
+    grid_coords(g, m0 < g.M ? m0 : 0, b0, z0, y0, x0);
+    rowbase = ((((long)b0 * g.Di + z0 * g.s) * g.Hi + y0 * g.s) * g.Wi + x0 * g.s) * g.Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xrow32[i] = rv[i] ? (unsigned)((rowoff[i] - rowbase) * 4) : OOB;
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) wvoff[i] = wvalid[i] ? (unsigned)(wrow[i] * 4) : OOB;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (rowbase + min_xoff)), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, OOB, 0x00020000);
   float4 ra[4], rbw[BN / 32];
   uint4 ra8[XH ? 4 : 1];        // XH: 8 bf16 per row as loaded
   float4 rbw2[XH ? BN / 32 : 1];  // XH: second half of the 8 weights per row (fp32 weights)
@@ -315,6 +346,10 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     tap_info(g, cls, t, dz, dy, dx, widx);
     ld_xoff = (((long)dz * g.Hi + dy) * g.Wi + dx) * g.Cin;
     ld_woff = (long)widx * g.Nout * g.Cin;
+    if constexpr (BL) {  // rows for which this tap falls outside the volume read zeros: an out-of-range offset
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xvoff[i] = (vmask[i] & 1ull) ? xrow32[i] : OOB;
+    }
   };
   if (!STEM) tap_offsets(0);
   auto load_tile = [&](int kt) {
@@ -362,6 +397,12 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
             rbw2[i] = (cok && wvalid[i]) ? *(const float4*)(wb + wrow[i] + 4) : make_float4(0, 0, 0, 0);
           }
         }
+      } else if constexpr (BL) {
+        const unsigned xs = (unsigned)((ld_xoff - min_xoff + cofs) * 4), ws = (unsigned)((ld_woff + cofs) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i], xs, 0));
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) rbw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff[i], ws, 0));
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1035,6 +1076,169 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
           const int n = n0 + wn * (TT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           const int c = c0 + wc * (TT / 2) + j * 32 + (lane & 31);
           if (n < g.Nout && c < Kc) atomicAdd(dW + ((long)widx[t] * g.Nout + n) * Kc + c, acc[t][i][j][r]);
+        }
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient, exact fp32, lean address stream
+// Same decomposition as k_wgrad (TT x TT weight tile, 32 voxels per step, NTAP taps share the staged dY tile) for
+// power-of-two class grids, rebuilt around one measurement (tools/micro/mfma_coexec.hip): while a wave streams fp32 MFMAs,
+// no other wave of its SIMD issues vector-ALU or vector-memory instructions, so every such instruction of the step is paid
+// in matrix-pipe time -- and k_wgrad spends ~250 of them per step and thread on coordinates, bounds and 64-bit addresses.
+// Here a thread owns ONE voxel row per step (its TT/32 float4 of dY and of each tap's X row), the coordinates come from
+// three shifts, row offsets are 32-bit multiply-adds relative to the block's first row, and the loads are buffer loads whose
+// out-of-range offset IS the zero fill of padding taps and of rows past the range: ~20 vector instructions per step.
+template <int TT, int NTAP>
+__global__ __launch_bounds__(CT) void k_wgrad_bl(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dW,
+                                                 IgemmGeom g, int tiles_c, int msplit, int tiles_total, int tap_groups) {
+  constexpr int KM = WG_KM;        // voxels per step
+  constexpr int QT = TT / 32;      // float4 per thread, row and tensor (8 threads per row)
+  constexpr int WT = TT / 64;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(NTAP == 1 || TT == 64, "multi-tap blocks use the 64x64 tile");
+  __shared__ __attribute__((aligned(16))) float Ys[KM * TT];
+  __shared__ __attribute__((aligned(16))) float Xs[NTAP * KM * TT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // see k_wgrad
+  const int bid_tap = bid % tap_groups;
+  const int bid_tile = (bid / tap_groups) % tiles_total;
+  const int bid_split = bid / (tap_groups * tiles_total);
+  const int n0 = (bid_tile / tiles_c) * TT, c0 = (bid_tile % tiles_c) * TT;
+  int cls = 0, tap = bid_tap * NTAP;
+  if (NTAP == 1) {
+    while (tap >= class_ntaps(g, cls)) {
+      tap -= class_ntaps(g, cls);
+      ++cls;
+    }
+  }
+  const int ntaps_cls = class_ntaps(g, cls);
+  const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+  int dz[NTAP], dy[NTAP], dx[NTAP], widx[NTAP];
+  bool tv[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    dz[t] = dy[t] = dx[t] = widx[t] = 0;
+    tv[t] = tap + t < ntaps_cls;
+    if (tv[t]) tap_info(g, cls, tap + t, dz[t], dy[t], dx[t], widx[t]);
+  }
+  const long chunk = ((g.M + msplit - 1) / msplit + KM - 1) / KM * KM;
+  const long mbeg = (long)bid_split * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int r = tid >> 3, q = tid & 7;  // this thread's row of the step and its first channel quad (then q + 8, ...)
+
+  // scalar: coordinates of the block's first row; every row offset below is taken relative to it (32-bit)
+  const unsigned m0u = (unsigned)(mbeg < g.M ? mbeg : 0);
+  const int x0 = (int)(m0u & (unsigned)(g.gw - 1)), y0 = (int)((m0u >> g.sw) & (unsigned)(g.gh - 1));
+  const int zb0 = (int)(m0u >> (g.sw + g.sh));  // b * gd + z
+  const long orow0 = ((long)(zb0 * g.os + pd) * g.Ho + y0 * g.os + ph) * g.Wo + x0 * g.os + pw;
+  // lowest X row any tap of this block can touch: the first row displaced by the smallest tap offset
+  long tmin = 0;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const long o = ((long)dz[t] * g.Hi + dy[t]) * g.Wi + dx[t];
+    tmin = (t == 0 || o < tmin) ? o : tmin;
+  }
+  const long xrow0 = ((long)(zb0 * g.s) * g.Hi + y0 * g.s) * g.Wi + x0 * g.s + tmin;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dY + orow0 * g.Nout + n0), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xrow0 * g.Cin + c0), 0, OOB, 0x00020000);
+  // per-axis strides of the two row indices, in rows (scalars)
+  const int oy_s = g.os * g.Wo, oz_s = g.os * g.Ho * g.Wo;            // dY row  = zb * oz_s + y * oy_s + x * os + const
+  const int xy_s = g.s * g.Wi, xz_s = g.s * g.Hi * g.Wi;              // X row   = zb * xz_s + y * xy_s + x * s  + tap + const
+  const int ybytes = g.Nout * 4, xbytes = g.Cin * 4;
+  int toff[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) toff[t] = (int)((((long)dz[t] * g.Hi + dy[t]) * g.Wi + dx[t]) - tmin);
+  const bool nfull = n0 + TT <= g.Nout, cfull = c0 + TT <= g.Cin;  // this block's channel ranges are whole (workgroup-uniform)
+
+  f32x16 acc[NTAP][WT][WT];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+  float4 vy[QT], vx[NTAP][QT];
+  auto load_step = [&](long mb) {
+    const unsigned m = (unsigned)mb + (unsigned)r;
+    const bool live = (long)m < mend;
+    const int x = (int)(m & (unsigned)(g.gw - 1)), y = (int)((m >> g.sw) & (unsigned)(g.gh - 1));
+    const int zb = (int)(m >> (g.sw + g.sh)), z = zb & (g.gd - 1);
+    const int dzb = zb - zb0, dyy = y - y0, dxx = x - x0;
+    unsigned yo = (unsigned)((dzb * oz_s + dyy * oy_s + dxx * g.os) * ybytes) + (unsigned)(q * 16);
+    yo = live ? yo : OOB;
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      const bool ok = nfull || n0 + (q + 8 * j) * 4 + 3 < g.Nout;
+      vy[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? yo + 128u * j : OOB, 0, 0));
+    }
+    const int xr = dzb * xz_s + dyy * xy_s + dxx * g.s;
+    const int zi = z * g.s, yi = y * g.s, xi = x * g.s;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      const bool in = live && tv[t] && (unsigned)(zi + dz[t]) < (unsigned)g.Di && (unsigned)(yi + dy[t]) < (unsigned)g.Hi &&
+                      (unsigned)(xi + dx[t]) < (unsigned)g.Wi;
+      const unsigned xo = in ? (unsigned)((xr + toff[t]) * xbytes) + (unsigned)(q * 16) : OOB;
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        const bool ok = cfull || c0 + (q + 8 * j) * 4 + 3 < g.Cin;
+        vx[t][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xo + 128u * j : OOB, 0, 0));
+      }
+    }
+  };
+
+  if (mbeg < mend) load_step(mbeg);
+  for (long mb = mbeg; mb < mend; mb += KM) {
+    __syncthreads();  // fragment reads of the previous step are done
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      *(float4*)(Ys + r * TT + (q + 8 * j) * 4) = vy[j];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) *(float4*)(Xs + (t * KM + r) * TT + (q + 8 * j) * 4) = vx[t][j];
+    }
+    __syncthreads();
+    if (mb + KM < mend) load_step(mb + KM);
+    float fa[2][WT], fb[2][NTAP][WT];
+    auto frag = [&](int set, int kk) {
+      const int mrow = 2 * kk + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < WT; ++i) fa[set][i] = Ys[mrow * TT + wn * (TT / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) fb[set][t][j] = Xs[(t * KM + mrow) * TT + wc * (TT / 2) + j * 32 + (lane & 31)];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < KM / 2; ++kk) {
+      const int cur = kk & 1;
+      if (kk + 1 < KM / 2) frag(cur ^ 1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][t][j], acc[t][i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    if (!tv[t]) continue;
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = n0 + wn * (TT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int c = c0 + wc * (TT / 2) + j * 32 + (lane & 31);
+          if (n < g.Nout && c < g.Cin) atomicAdd(dW + ((long)widx[t] * g.Nout + n) * g.Cin + c, acc[t][i][j][e]);
         }
   }
 }
@@ -2089,6 +2293,9 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
   // bf16 packed weights as well: tiles loaded straight into LDS (HP_IGEMM_GL=0 keeps the register-staged tiles: A/B runs)
   static const bool gl_on = !(getenv("HP_IGEMM_GL") && atoi(getenv("HP_IGEMM_GL")) == 0);
   const bool gl = XH && g.wh && gl_on;
+  // exact-fp32 tiles with whole 32-channel K tiles: buffer loads (HP_IGEMM_BL=0 keeps the flat loads: A/B runs)
+  static const bool bl_on = !(getenv("HP_IGEMM_BL") && atoi(getenv("HP_IGEMM_BL")) == 0);
+  const bool bl = NP == 0 && !STEM && bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 * (g.mode == MODE_DECONV ? 8 : 1) < (1l << 31);
   if (g.Nout > 64) {
     const unsigned tn = (unsigned)((g.Nout + 127) / 128);
     IgemmGeom gg = g;
@@ -2100,11 +2307,23 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
         return;
       }
     }
+    if constexpr (NP == 0 && !STEM) {
+      if (bl) {
+        hipLaunchKernelGGL((k_igemm<128, false, STATS, 0, false, false, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
+        return;
+      }
+    }
     hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP, XH>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
   } else if (g.Nout > 32) {
     if constexpr (XH) {
       if (gl) {
         hipLaunchKernelGGL((k_igemm<64, STEM, STATS, NP, true, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
+        return;
+      }
+    }
+    if constexpr (NP == 0 && !STEM) {
+      if (bl) {
+        hipLaunchKernelGGL((k_igemm<64, false, STATS, 0, false, false, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
         return;
       }
     }
@@ -2378,6 +2597,23 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, c
   dim3 grid((unsigned)((long)tiles_total * tap_groups * msplit));
   {
     HP_PROF("conv_wgrad", st);
+    static const bool wbl_on = !(getenv("HP_WGRAD_BL") && atoi(getenv("HP_WGRAD_BL")) == 0);
+    // lean fp32 kernel: power-of-two class grid, whole channel quads, and every row offset of a block within 2^31 bytes
+    const long chunk_rows = (g.M + msplit - 1) / msplit + WG_KM;
+    const long span_y = chunk_rows * g.os * g.os * g.os * (long)g.Nout * 4, span_x = (chunk_rows * g.s * g.s * g.s + 4l * g.Hi * g.Wi) * (long)g.Cin * 4;
+    const bool exact_grid = g.Di == g.gd * g.s && g.Hi == g.gh * g.s && g.Wi == g.gw * g.s && g.Do == g.gd * g.os &&
+                            g.Ho == g.gh * g.os && g.Wo == g.gw * g.os;
+    if (wbl_on && !p.stem && p.planes == 0 && !xh && !dyh && g.sw >= 0 && exact_grid && g.Nout % 4 == 0 && g.Cin % 4 == 0 &&
+        span_y < (1l << 30) && span_x < (1l << 30)) {
+      if (TT == 128)
+        hipLaunchKernelGGL((k_wgrad_bl<128, 1>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+      else if (multitap)
+        hipLaunchKernelGGL((k_wgrad_bl<64, 4>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+      else
+        hipLaunchKernelGGL((k_wgrad_bl<64, 1>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+      HP_CHECK_HIP(hipGetLastError());
+      return HP_OK;
+    }
 #define HP_WGRAD_P(STEM_, TT_, NTAP_, NP_)                                                                   \
   hipLaunchKernelGGL((k_wgrad<STEM_, TT_, NTAP_, NP_>), grid, dim3(CT), 0, st, x, dy, dw_packed, g, tiles_c, \
                      (int)msplit, tiles_total, tap_groups)
