@@ -1088,7 +1088,10 @@ __global__ __launch_bounds__(CT) void k_wgrad(const void* __restrict__ Xv, const
 // Here a thread owns ONE voxel row per step (its TT/32 float4 of dY and of each tap's X row), the coordinates come from
 // three shifts, row offsets are 32-bit multiply-adds relative to the block's first row, and the loads are buffer loads whose
 // out-of-range offset IS the zero fill of padding taps and of rows past the range: ~20 vector instructions per step.
-template <int TT, int NTAP>
+// UNI (class grids at least 8 wide): the 8 rows a wave loads per step are 8 consecutive x positions of one (b, z, y) line,
+// so that line's coordinates, its bounds tests and both row offsets are SCALAR work (the wave's scalar offset of the buffer
+// loads); per lane there remain a fixed offset and, per tap, the x bound of the line's two ends: 3 vector instructions.
+template <int TT, int NTAP, bool UNI>
 __global__ __launch_bounds__(CT) void k_wgrad_bl(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dW,
                                                  IgemmGeom g, int tiles_c, int msplit, int tiles_total, int tap_groups) {
   constexpr int KM = WG_KM;        // voxels per step
@@ -1162,7 +1165,38 @@ __global__ __launch_bounds__(CT) void k_wgrad_bl(const float* __restrict__ X, co
         for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
 
   float4 vy[QT], vx[NTAP][QT];
+  // UNI: this wave's 8 rows of a step start at row 8 * wv; lane part of every offset (x position lx of the line, channel quad q)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lx = (tid >> 3) & 7;
+  const unsigned ylane = (unsigned)(lx * g.os * ybytes + q * 16), xlane = (unsigned)(lx * g.s * xbytes + q * 16);
+  const int lxs = lx * g.s;
   auto load_step = [&](long mb) {
+    if constexpr (UNI) {
+      const unsigned mw = (unsigned)mb + 8u * (unsigned)wv;  // first of this wave's 8 rows: a multiple of 8 (scalar)
+      const bool live = (long)mw < mend;                    // the range ends on a multiple of 8: all 8 rows or none
+      const int xw = (int)(mw & (unsigned)(g.gw - 1)), y = (int)((mw >> g.sw) & (unsigned)(g.gh - 1));
+      const int zb = (int)(mw >> (g.sw + g.sh)), z = zb & (g.gd - 1);
+      const int dzb = zb - zb0, dyy = y - y0, dxx = xw - x0;
+      const unsigned ys = (unsigned)((dzb * oz_s + dyy * oy_s + dxx * g.os) * ybytes);
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        const bool ok = live && (nfull || n0 + (q + 8 * j) * 4 + 3 < g.Nout);
+        vy[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? ylane + 128u * j : OOB, ys, 0));
+      }
+      const int xr = dzb * xz_s + dyy * xy_s + dxx * g.s;
+      const int zi = z * g.s, yi = y * g.s, xi = xw * g.s;
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const bool line = live && tv[t] && (unsigned)(zi + dz[t]) < (unsigned)g.Di && (unsigned)(yi + dy[t]) < (unsigned)g.Hi;  // scalar
+        const bool in = line && (unsigned)(lxs + xi + dx[t]) < (unsigned)g.Wi;
+        const unsigned xs = (unsigned)((xr + toff[t]) * xbytes);
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+          const bool ok = in && (cfull || c0 + (q + 8 * j) * 4 + 3 < g.Cin);
+          vx[t][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xlane + 128u * j : OOB, xs, 0));
+        }
+      }
+      return;
+    }
     const unsigned m = (unsigned)mb + (unsigned)r;
     const bool live = (long)m < mend;
     const int x = (int)(m & (unsigned)(g.gw - 1)), y = (int)((m >> g.sw) & (unsigned)(g.gh - 1));
@@ -2605,12 +2639,20 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, c
                             g.Ho == g.gh * g.os && g.Wo == g.gw * g.os;
     if (wbl_on && !p.stem && p.planes == 0 && !xh && !dyh && g.sw >= 0 && exact_grid && g.Nout % 4 == 0 && g.Cin % 4 == 0 &&
         span_y < (1l << 30) && span_x < (1l << 30)) {
-      if (TT == 128)
-        hipLaunchKernelGGL((k_wgrad_bl<128, 1>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
-      else if (multitap)
-        hipLaunchKernelGGL((k_wgrad_bl<64, 4>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
-      else
-        hipLaunchKernelGGL((k_wgrad_bl<64, 1>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, tiles_c, (int)msplit, tiles_total, tap_groups);
+#define HP_WBL(TT_, NTAP_)                                                                                                       \
+  do {                                                                                                                           \
+    if (uni)                                                                                                                     \
+      hipLaunchKernelGGL((k_wgrad_bl<TT_, NTAP_, true>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, \
+                         tiles_c, (int)msplit, tiles_total, tap_groups);                                                         \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((k_wgrad_bl<TT_, NTAP_, false>), grid, dim3(CT), 0, st, (const float*)x, (const float*)dy, dw_packed, g, \
+                         tiles_c, (int)msplit, tiles_total, tap_groups);                                                         \
+  } while (0)
+      const bool uni = g.gw >= 8 && !(getenv("HP_WGRAD_UNI") && atoi(getenv("HP_WGRAD_UNI")) == 0);
+      if (TT == 128) HP_WBL(128, 1);
+      else if (multitap) HP_WBL(64, 4);
+      else HP_WBL(64, 1);
+#undef HP_WBL
       HP_CHECK_HIP(hipGetLastError());
       return HP_OK;
     }
