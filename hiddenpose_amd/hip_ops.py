@@ -638,6 +638,15 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
     desc.io &= ~HP_IO_W
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
     side = _wgrad_side_stream(x.device)
+    if side is not None:
+        # The side-stream hand-over is safe only where nothing reads `dw` on the main stream before the join: a leaf whose
+        # gradient autograd merely adopts (or that we accumulate ourselves, below).  A tensor hook receives the gradient, a
+        # post-accumulate hook may read it (unless the gradient is pre-allocated, which is the accumulate path below), and a
+        # weight used twice in one graph has its two gradients SUMMED by autograd on the main stream: main-stream path.
+        hooked = bool(getattr(w, "_backward_hooks", None)) or \
+            (bool(getattr(w, "_post_accumulate_grad_hooks", None)) and not (w.is_leaf and w.grad is not None))
+        if (not w.is_leaf) or hooked or getattr(w, "_hp_shared", False):
+            side = None
     if side is None:
         dwp = torch.empty(n, dtype=torch.float32, device=x.device)
         _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), st),
@@ -690,6 +699,8 @@ class _ConvBnAct(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None, res_link=None):
         L = _lib.lib()
         x = x.contiguous()
+        if _WGRAD_ASYNC and torch.is_grad_enabled():
+            w._hp_uses = getattr(w, "_hp_uses", 0) + 1   # a weight used twice in one graph must not take the side stream
         cout = w.shape[1] if transposed else w.shape[0]
         desc = _desc(x, cout, k, stride, pad, transposed)
         do, ho, wo = _out_dims(desc)
@@ -800,7 +811,14 @@ class _ConvBnAct(torch.autograd.Function):
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:
                 addend, addend_mask, last = link_in.take()
+            uses = getattr(w, "_hp_uses", 0)
+            if uses > 1:
+                w._hp_shared = True        # every backward of this weight in this pass stays on the main stream
             dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask)
+            if uses > 0:
+                w._hp_uses = uses - 1
+                if uses == 1:
+                    w._hp_shared = False
             if not last:           # first of two convolutions reading the block input: park the partial sum
                 link_in.g, dx = dx, None
             gres = g

@@ -538,3 +538,34 @@ def test_conv_bn_act_unit_bf16_storage(with_res):
     if with_res:   # g = dy (.) [y > 0]: z rounded to bf16 moves outputs within 2^-9 of zero across it (mask flips)
         assert rel_l2(b[2], a[2]) < 4e-2
     assert rel_l2(b[3], a[3]) < 3e-2 and rel_l2(b[4], a[4]) < 3e-2 and rel_l2(b[5], a[5]) < 3e-2
+
+
+def test_side_stream_weight_gradient_with_a_tensor_hook_or_shared_weight():
+    """with weight gradients on the side stream (set_wgrad_async) a weight that carries a tensor hook, or that is
+    used twice in one graph (autograd then SUMS the two gradients on the main stream), must not be handed to autograd before
+    the side stream has written it: such weights fall back to the main-stream path.  Results equal the serial mode."""
+    from torch import nn
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 6, 6, 8, 64, generator=g).cuda()
+
+    def run(async_on):
+        conv = nn.Conv3d(64, 64, 3, padding=1, bias=False).cuda()
+        bn = nn.BatchNorm3d(64).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=torch.Generator().manual_seed(9)).cuda() * 0.05)
+        seen = []
+        conv.weight.register_hook(lambda gr: seen.append(float(gr.double().norm())))   # reads the gradient on the main stream
+        prev = ops.set_wgrad_async(async_on)
+        try:
+            y = ops.conv_bn_act(ops.conv_bn_act(x, conv, bn), conv, bn)               # the same weight twice in one graph
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_wgrad_async(prev)
+        return conv.weight.grad.clone(), seen
+
+    g0, s0 = run(False)
+    g1, s1 = run(True)
+    assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
+    assert len(s0) == len(s1) and all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(s0, s1))

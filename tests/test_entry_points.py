@@ -106,6 +106,38 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
 
 
 @pytest.mark.gpu
+def test_bf16_storage_mode_trains_like_fp32():
+    """BASELINE configs[2]'s per-GPU arithmetic (`bf16s`: bf16 matrix cores, bf16 activations / activation gradients in HBM,
+    fp32 LCT, statistics, weights and optimizer) against the fp32 mode as TRAINING, not as one step: twenty Adam steps on
+    one fixed 128^3 batch from the same initialisation (reference init, seed 410).  Both losses must fall, the bf16s curve
+    must track the fp32 one step by step (<= 8 % apart: one bf16 step perturbs a gradient by ~1e-2) and end within 5 %."""
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.NlosPose import NlosPose
+    from hiddenpose_amd.train_epoch import build_training, seed_everything, train_step
+
+    meas = hpt.synthetic_meas(2, 128, 128, "transient", seed=1).cuda()
+    vol = hpt.synthetic_vol(2, 128, 128, seed=2).cuda()
+    joints = hpt.synthetic_joints(2, 64, seed=3).cuda()
+    curves = {}
+    for prec in ("fp32", "bf16s"):
+        seed_everything(410)
+        cfg = make_cfg(128, 128, conv_precision=prec)
+        model = NlosPose(cfg).cuda().train()
+        criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+        curves[prec] = [float(train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints)[0]) for _ in range(20)]
+        del model, optimizer
+        torch.cuda.empty_cache()
+    a, b = np.array(curves["fp32"]), np.array(curves["bf16s"])
+    print("fp32 :", " ".join(f"{v:.4g}" for v in a))
+    print("bf16s:", " ".join(f"{v:.4g}" for v in b))
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+    assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]
+    assert np.abs(b / a - 1).max() < 0.08, (a, b)
+    assert abs(b[-1] / a[-1] - 1) < 0.05
+
+
+@pytest.mark.gpu
 def test_prefetching_loader_matches_the_plain_loader(tmp_path):
     """PrefetchingLoader (host threads -> pinned memory -> side-stream ingest) yields exactly the batches of the in-process
     loader, in order; an unreadable measurement is replaced by sample 0 (meas, joints, id) with its own volume kept."""
