@@ -1277,6 +1277,174 @@ __global__ __launch_bounds__(CT) void k_wgrad_bl(const float* __restrict__ X, co
   }
 }
 
+// The same lean address stream for the bf16-storage weight gradient (X and dY bf16 in memory, v_mfma_f32_32x32x16_bf16,
+// fragments through ds_read_b64_tr_b16 as in k_wgrad's XH path).  There the step is only 8 MFMAs per wave (256 cycles of
+// matrix pipe) against ~120 vector instructions of coordinate and address arithmetic per thread: the kernel was bound by its
+// own address stream.  Wave-uniform rows (see k_wgrad_bl, UNI): a wave's 8 rows per pass are 8 consecutive x positions of one
+// line, everything but the x bound of a tap is scalar, and the 16-byte loads are buffer loads with the zero fill in the range
+// check.  KMH voxels per step (8 threads per row, KMH / 32 passes).
+template <int TT, int NTAP, int KMH>
+__global__ __launch_bounds__(CT) void k_wgrad_blh(const unsigned short* __restrict__ X, const unsigned short* __restrict__ dY,
+                                                  float* __restrict__ dW, IgemmGeom g, int tiles_c, int msplit, int tiles_total,
+                                                  int tap_groups) {
+  constexpr int QT = TT / 64;      // 16-byte loads (8 bf16) per thread, row and tensor: 8 threads cover a row of TT channels
+  constexpr int NPASS = KMH / 32;  // 32 rows per pass
+  constexpr int WT = TT / 64;
+  constexpr int LDT = TT + 32;     // bf16 row stride: 16 dwords mod 32 (see k_wgrad)
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(NTAP == 1 || TT == 64, "multi-tap blocks use the 64x64 tile");
+  __shared__ __attribute__((aligned(16))) __bf16 Yh[KMH * LDT];
+  __shared__ __attribute__((aligned(16))) __bf16 Xh[NTAP * KMH * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) bid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int bid_tap = bid % tap_groups;
+  const int bid_tile = (bid / tap_groups) % tiles_total;
+  const int bid_split = bid / (tap_groups * tiles_total);
+  const int n0 = (bid_tile / tiles_c) * TT, c0 = (bid_tile % tiles_c) * TT;
+  int cls = 0, tap = bid_tap * NTAP;
+  if (NTAP == 1) {
+    while (tap >= class_ntaps(g, cls)) {
+      tap -= class_ntaps(g, cls);
+      ++cls;
+    }
+  }
+  const int ntaps_cls = class_ntaps(g, cls);
+  const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+  int dz[NTAP], dy[NTAP], dx[NTAP], widx[NTAP];
+  bool tv[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    dz[t] = dy[t] = dx[t] = widx[t] = 0;
+    tv[t] = tap + t < ntaps_cls;
+    if (tv[t]) tap_info(g, cls, tap + t, dz[t], dy[t], dx[t], widx[t]);
+  }
+  const long chunk = ((g.M + msplit - 1) / msplit + KMH - 1) / KMH * KMH;
+  const long mbeg = (long)bid_split * chunk, mend = mbeg + chunk < g.M ? mbeg + chunk : g.M;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int r = tid >> 3, q = tid & 7;
+  const unsigned m0u = (unsigned)(mbeg < g.M ? mbeg : 0);
+  const int x0 = (int)(m0u & (unsigned)(g.gw - 1)), y0 = (int)((m0u >> g.sw) & (unsigned)(g.gh - 1));
+  const int zb0 = (int)(m0u >> (g.sw + g.sh));
+  const long orow0 = ((long)(zb0 * g.os + pd) * g.Ho + y0 * g.os + ph) * g.Wo + x0 * g.os + pw;
+  long tmin = 0;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const long o = ((long)dz[t] * g.Hi + dy[t]) * g.Wi + dx[t];
+    tmin = (t == 0 || o < tmin) ? o : tmin;
+  }
+  const long xrow0 = ((long)(zb0 * g.s) * g.Hi + y0 * g.s) * g.Wi + x0 * g.s + tmin;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dY + orow0 * g.Nout + n0), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xrow0 * g.Cin + c0), 0, OOB, 0x00020000);
+  const int oy_s = g.os * g.Wo, oz_s = g.os * g.Ho * g.Wo, xy_s = g.s * g.Wi, xz_s = g.s * g.Hi * g.Wi;
+  const int ybytes = g.Nout * 2, xbytes = g.Cin * 2;
+  int toff[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) toff[t] = (int)((((long)dz[t] * g.Hi + dy[t]) * g.Wi + dx[t]) - tmin);
+  const bool nfull = n0 + TT <= g.Nout, cfull = c0 + TT <= g.Cin;
+
+  f32x16 acc[NTAP][WT][WT];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+  uint4 hy[NPASS][QT], hx[NPASS][NTAP][QT];
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lx = (tid >> 3) & 7;
+  const unsigned ylane = (unsigned)(lx * g.os * ybytes + q * 16), xlane = (unsigned)(lx * g.s * xbytes + q * 16);
+  const int lxs = lx * g.s;
+  auto load_step = [&](long mb) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const unsigned mw = (unsigned)mb + 32u * ps + 8u * (unsigned)wv;  // this wave's 8 rows of the pass (scalar, multiple of 8)
+      const bool live = (long)mw < mend;
+      const int xw = (int)(mw & (unsigned)(g.gw - 1)), y = (int)((mw >> g.sw) & (unsigned)(g.gh - 1));
+      const int zb = (int)(mw >> (g.sw + g.sh)), z = zb & (g.gd - 1);
+      const int dzb = zb - zb0, dyy = y - y0, dxx = xw - x0;
+      const unsigned ys = (unsigned)((dzb * oz_s + dyy * oy_s + dxx * g.os) * ybytes);
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        const bool ok = live && (nfull || n0 + (q + 8 * j) * 8 + 7 < g.Nout);
+        hy[ps][j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? ylane + 128u * j : OOB, ys, 0));
+      }
+      const int xr = dzb * xz_s + dyy * xy_s + dxx * g.s;
+      const int zi = z * g.s, yi = y * g.s, xi = xw * g.s;
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const bool line = live && tv[t] && (unsigned)(zi + dz[t]) < (unsigned)g.Di && (unsigned)(yi + dy[t]) < (unsigned)g.Hi;
+        const bool in = line && (unsigned)(lxs + xi + dx[t]) < (unsigned)g.Wi;
+        const unsigned xs = (unsigned)((xr + toff[t]) * xbytes);
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+          const bool ok = in && (cfull || c0 + (q + 8 * j) * 8 + 7 < g.Cin);
+          hx[ps][t][j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xlane + 128u * j : OOB, xs, 0));
+        }
+      }
+    }
+  };
+
+  const int gq = lane >> 4, li = lane & 15;
+  const int trow = 8 * (gq >> 1) + (li >> 2), tcol = 16 * (gq & 1) + 4 * (li & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  auto tr8 = [&](const __bf16* base) -> bf16x8 {
+    union {
+      s16x4 h[2];
+      bf16x8 f;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * LDT));
+    return u.f;
+  };
+  if (mbeg < mend) load_step(mbeg);
+  for (long mb = mbeg; mb < mend; mb += KMH) {
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        *(uint4*)(Yh + (32 * ps + r) * LDT + (q + 8 * j) * 8) = hy[ps][j];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) *(uint4*)(Xh + (t * KMH + 32 * ps + r) * LDT + (q + 8 * j) * 8) = hx[ps][t][j];
+      }
+    __syncthreads();
+    if (mb + KMH < mend) load_step(mb + KMH);
+#pragma unroll
+    for (int ks = 0; ks < KMH / 16; ++ks) {
+      bf16x8 ha[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) ha[i] = tr8(Yh + (ks * 16 + trow) * LDT + wn * (TT / 2) + i * 32 + tcol);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        bf16x8 hb[WT];
+#pragma unroll
+        for (int j = 0; j < WT; ++j) hb[j] = tr8(Xh + (t * KMH + ks * 16 + trow) * LDT + wc * (TT / 2) + j * 32 + tcol);
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[t][i][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    if (!tv[t]) continue;
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = n0 + wn * (TT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int c = c0 + wc * (TT / 2) + j * 32 + (lane & 31);
+          if (n < g.Nout && c < g.Cin) atomicAdd(dW + ((long)widx[t] * g.Nout + n) * g.Cin + c, acc[t][i][j][e]);
+        }
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient of a dense 1^3 convolution, thin side
 // dW[n][c] = sum_m dY[m][n] * X[m][c] when one side has 64 channels and the other 256 (layer-1 Bottlenecks): the
 // square 64 x 64 tile of k_wgrad leaves every wave a single MFMA tile (2 fragment reads per MFMA, ~80 TFLOP/s, and
@@ -2653,6 +2821,27 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, c
       else if (multitap) HP_WBL(64, 4);
       else HP_WBL(64, 1);
 #undef HP_WBL
+      HP_CHECK_HIP(hipGetLastError());
+      return HP_OK;
+    }
+    static const int wblh_km = getenv("HP_WGRAD_BLH") ? atoi(getenv("HP_WGRAD_BLH")) : 32;   // 0: off; 32 / 64: voxels per step
+    if (wblh_km > 0 && !p.stem && p.planes == 1 && xh && dyh && g.sw >= 0 && g.gw >= 8 && exact_grid && g.Cin % 8 == 0 &&
+        g.Nout % 8 == 0 && span_y < (1l << 30) && span_x < (1l << 30)) {
+      const unsigned short* xs_ = (const unsigned short*)x;
+      const unsigned short* ys_ = (const unsigned short*)dy;
+#define HP_WBLH(TT_, NTAP_)                                                                                                          \
+  do {                                                                                                                                \
+    if (wblh_km == 64)                                                                                                                \
+      hipLaunchKernelGGL((k_wgrad_blh<TT_, NTAP_, 64>), grid, dim3(CT), 0, st, xs_, ys_, dw_packed, g, tiles_c, (int)msplit,           \
+                         tiles_total, tap_groups);                                                                                    \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((k_wgrad_blh<TT_, NTAP_, 32>), grid, dim3(CT), 0, st, xs_, ys_, dw_packed, g, tiles_c, (int)msplit,           \
+                         tiles_total, tap_groups);                                                                                    \
+  } while (0)
+      if (TT == 128) HP_WBLH(128, 1);
+      else if (multitap) HP_WBLH(64, 4);
+      else HP_WBLH(64, 1);
+#undef HP_WBLH
       HP_CHECK_HIP(hipGetLastError());
       return HP_OK;
     }
