@@ -74,7 +74,6 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   const int co = cog * 4 + sub;
   const bool co_ok = co < cout;
   const long cs = (long)D * H * W;
-  const float* gch = g + ((long)b * cout + (co_ok ? co : 0)) * cs;
   const float* xb = x + ((long)b * cin + cig * 4) * cs;
   const bool want_db = cig == 0;
 
@@ -82,8 +81,10 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   // (the LDS offset IS e) comes from offset soff[k] inside the channel-0 z-plane, or is zero when bit k of smask
   // is clear (zero padding, columns 66/67, channels past cin).
   constexpr int SK = (WG_PLANE + 255) / 256;
-  int soff[SK];
-  unsigned smask = 0;
+  // buffer loads (see k_dconv3_mfma): fixed per-thread byte offsets, out-of-range = the zero padding, plane in the scalar offset
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+  unsigned soff[SK];
 #pragma unroll
   for (int k = 0; k < SK; ++k) {
     const int e = tid + 256 * k;
@@ -98,8 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
     } else {
       ok = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
     }
-    soff[k] = ok ? (int)((long)c * cs + (long)yy * W + xx) : 0;
-    smask |= ok ? (1u << k) : 0u;
+    soff[k] = ok ? (unsigned)(((long)c * cs + (long)yy * W + xx) * 4) : OOB;
   }
   // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
   // (stage_store) after it, so the global-memory latency hides behind the MFMAs
@@ -107,9 +107,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
     int zz = zp;
     bool zok = (unsigned)zz < (unsigned)D;
     if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
-    const float* src = xb + (long)zz * H * W;
+    if (zok) {
+      const unsigned zs = (unsigned)((long)zz * H * W * 4);
 #pragma unroll
-    for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+      for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < SK; ++k) v[k] = 0.f;
+    }
   };
   auto stage_store = [&](int zp, const float (&v)[SK]) {
     float* dst = ring + (zp & 3) * WG_PLANE + tid;
@@ -136,11 +141,23 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   // this lane's offset inside a plane for row r, run q: (sub * PY + (2*wave + r) + dy) * PX + q*16 + blk + dx
   const int lbase = (sub * WG_PY + 2 * wave) * WG_PX + blk;
   // g of one plane: 8 (row, run) values per lane
+  // g through a buffer descriptor at this workgroup's 4 output channels: lane part (channel sub, x run) fixed, row and plane scalar
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, OOB, 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  unsigned goff[4];
+#pragma unroll
+  for (int qx = 0; qx < 4; ++qx) {
+    const int xv = x0 + qx * 16 + blk;
+    goff[qx] = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;
+  }
   auto g_load = [&](int z, float (&gv)[8]) {
 #pragma unroll
     for (int rq = 0; rq < 8; ++rq) {
-      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
-      gv[rq] = (co_ok && z < ze && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
+      const int y = y0 + 2 * wv + (rq >> 2);   // scalar
+      if (z < ze && y < H)
+        gv[rq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, goff[rq & 3], (unsigned)(((long)z * H + y) * W * 4), 0));
+      else
+        gv[rq] = 0.f;
     }
   };
   auto multiply = [&](int z, const float (&gv)[8]) {
@@ -236,13 +253,13 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   const int co = cog * 4 + sub;
   const bool co_ok = co < cout;
   const long cs = (long)D * H * W;
-  const float* gch = g + ((long)b * cout + (co_ok ? co : 0)) * cs;
   const float* xb = x + (long)b * cs;
   for (int u = tid; u < 4 * 28 * 16; u += 256) (&part[0][0])[u] = 0.f;
 
   constexpr int SK = (W1_PLANE + 255) / 256;
-  int soff[SK];
-  unsigned smask = 0;
+  constexpr unsigned OOB = 0x80000000u;   // buffer loads as in k_dconv3_wgrad_mfma
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+  unsigned soff[SK];
 #pragma unroll
   for (int k = 0; k < SK; ++k) {
     const int e = tid + 256 * k;
@@ -255,8 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
     } else {
       ok = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
     }
-    soff[k] = ok ? (int)((long)yy * W + xx) : 0;
-    smask |= ok ? (1u << k) : 0u;
+    soff[k] = ok ? (unsigned)(((long)yy * W + xx) * 4) : OOB;
   }
   // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
   // (stage_store) after it, so the global-memory latency hides behind the MFMAs
@@ -264,9 +280,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
     int zz = zp;
     bool zok = (unsigned)zz < (unsigned)D;
     if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
-    const float* src = xb + (long)zz * H * W;
+    if (zok) {
+      const unsigned zs = (unsigned)((long)zz * H * W * 4);
 #pragma unroll
-    for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+      for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < SK; ++k) v[k] = 0.f;
+    }
   };
   auto stage_store = [&](int zp, const float (&v)[SK]) {
     float* dst = ring + (zp & 3) * W1_PLANE + tid;
@@ -300,11 +321,23 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   }
   __syncthreads();
   const int lbase = (2 * wave) * WG_PX + blk;
+  // g through a buffer descriptor at this workgroup's 4 output channels: lane part (channel sub, x run) fixed, row and plane scalar
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, OOB, 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  unsigned goff[4];
+#pragma unroll
+  for (int qx = 0; qx < 4; ++qx) {
+    const int xv = x0 + qx * 16 + blk;
+    goff[qx] = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;
+  }
   auto g_load = [&](int z, float (&gv)[8]) {
 #pragma unroll
     for (int rq = 0; rq < 8; ++rq) {
-      const int y = y0 + 2 * wave + (rq >> 2), xv = x0 + (rq & 3) * 16 + blk;
-      gv[rq] = (co_ok && z < ze && y < H && xv < W) ? gch[((long)z * H + y) * W + xv] : 0.f;
+      const int y = y0 + 2 * wv + (rq >> 2);   // scalar
+      if (z < ze && y < H)
+        gv[rq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, goff[rq & 3], (unsigned)(((long)z * H + y) * W * 4), 0));
+      else
+        gv[rq] = 0.f;
     }
   };
   auto multiply = [&](int z, const float (&gv)[8]) {
@@ -438,6 +471,12 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
   const int zb = bz * zchunk, ze = min(Do, zb + zchunk);
   const long ics = (long)Di * Hi * Wi, ocs = (long)Do * Ho * Wo;
   constexpr int SK = (WG_PLANE + 255) / 256;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const bool xin = x0 + lane < Wo;
+  const unsigned xoff = xin ? (unsigned)((x0 + lane) * 4) : 0x80000000u;
+  const long ybase = ((long)b * cout + cog * 4) * ocs;   // this workgroup's 4 output channels: offsets within them fit 31 bits
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
 
   for (int c0 = 0; c0 < cin; c0 += 4) {
     const int nci = min(4, cin - c0);
@@ -451,9 +490,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
         v = w[(long)(cog * 4 + co) * wsco + (long)(c0 + ci) * wsci + (flip ? 26 - tap : tap)];
       wl[e] = v;
     }
-    // staging map (see the weight-gradient kernel): element e = tid + 256 k of the [4][10][68] plane image
-    int soff[SK];
-    unsigned smask = 0;
+    // staging map (see the weight-gradient kernel): element e = tid + 256 k of the [4][10][68] plane image.  The plane is
+    // fetched with BUFFER loads: descriptor base = this sweep's 4-channel chunk, per-thread byte offset fixed for the sweep
+    // (cells outside the volume carry an out-of-range offset: the hardware returns the zero padding), the plane in the scalar
+    // offset -- no vector address arithmetic per plane (while a wave streams fp32 MFMAs the other waves of its SIMD issue no
+    // vector-ALU instruction: tools/micro/mfma_coexec.hip; each one here is paid in matrix-pipe time).
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+    unsigned soff[SK];
 #pragma unroll
     for (int k = 0; k < SK; ++k) {
       const int e = tid + 256 * k;
@@ -468,8 +512,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
       } else {
         ok = ok && (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
       }
-      soff[k] = ok ? (int)((long)c * ics + (long)yy * Wi + xx) : 0;
-      smask |= ok ? (1u << k) : 0u;
+      soff[k] = ok ? (unsigned)(((long)c * ics + (long)yy * Wi + xx) * 4) : OOB;
     }
     // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
     // (stage_store) after it, so the global-memory latency hides behind the MFMAs
@@ -477,9 +520,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
       int zz = zin;
       bool zok = (unsigned)zz < (unsigned)Di;
       if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
-      const float* src = xb + (long)zz * Hi * Wi;
+      if (zok) {  // workgroup-uniform
+        const unsigned zs = (unsigned)((long)zz * Hi * Wi * 4);
 #pragma unroll
-      for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+        for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+      } else {
+#pragma unroll
+        for (int k = 0; k < SK; ++k) v[k] = 0.f;
+      }
     };
     auto stage_store = [&](int zin, const float (&v)[SK]) {
       float* dst = ring + (zin & 3) * WG_PLANE + tid;
@@ -532,24 +580,27 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
                 acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[(dz * 3 + dy) * 3 + dx], pl[dy * WG_PX + dx], acc[r], 0, 0, 0);
           }
       }
-      // lane l holds out[co0 + i][row][x0 + l] in acc[row][i]
+      // lane l holds out[co0 + i][row][x0 + l] in acc[row][i].  Buffer stores / loads: the lane part of the address is fixed
+      // for the whole kernel (x position; beyond the row: out of range = dropped / zero), row, plane and channel are scalar.
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int oy = y0 + 2 * wave + r, ox = x0 + lane;
-        if (oy < Ho && ox < Wo) {
+        const int oy = y0 + 2 * wv + r;   // scalar
+        if (oy < Ho) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int oc = cog * 4 + i;
             if (oc < cout) {
-              const long o = ((long)b * cout + oc) * ocs + ((long)z * Ho + oy) * Wo + ox;
-              float v = acc[r][i] + (c0 == 0 ? (bias ? bias[oc] : 0.f) : y[o]);
+              const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
+              float v = acc[r][i] + (c0 == 0 ? (bias ? bias[oc] : 0.f)
+                                             : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, xoff, so, 0)));
               if (c0 + 4 >= cin) {  // last channel chunk: the sum is complete -> residual, activation, statistics
-                if (res) v += res[o];
+                if (res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, xoff, so, 0));
                 if (slope != 1.0f) v = v > 0.f ? v : v * slope;
-                st1[i] += v;
-                st2[i] += v * v;
+                const float vs = xin ? v : 0.f;   // lanes beyond the row do not count
+                st1[i] += vs;
+                st2[i] += vs * vs;
               }
-              y[o] = v;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, so, 0);
             }
           }
         }
