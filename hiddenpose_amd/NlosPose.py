@@ -28,7 +28,10 @@ class NlosPose(nn.Module):
             raise NotImplementedError("a pickled autoencoder module cannot be adopted; load its state_dict into "
                                       "`.autoencoder` after construction")
         if m.BACKBONE != "posenet3d_50":
-            raise NotImplementedError(f"backbone {m.BACKBONE!r} is not built (the reference's config selects posenet3d_50)")
+            # models/NlosPose.py:41-45 constructs VisibleNet + the 2-D posenet for 'posenet2d', but its forward (:49-59) never
+            # calls vis_net and feeds the 5-D volume to a Conv2d: there is no runnable reference behaviour to reproduce
+            raise NotImplementedError(f"backbone {m.BACKBONE!r} is not built: the reference's own forward cannot run with it "
+                                      "(models/NlosPose.py:49-59); its config selects posenet3d_50")
         self.time_begin, self.time_end = 0, m.TIME_SIZE
         self.feature_extraction = FeatureExtraction(m.BASEDIM, m.IN_CHANNELS, stride=1)
         self.feature_propagation = FeaturePropagation(image_size=m.IMAGE_SIZE[0], time_size=m.TIME_SIZE,
