@@ -626,6 +626,22 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     static_assert(64 * LDO <= ARENA, "staging tile must fit the arena");
     static_assert(C::WM == 2 && C::TM == 2, "epilogue assumes 2 waves x 2 MFMA tiles along M");
     const bool vec_ok = (g.Nout & 3) == 0;
+    // Whole tiles of a dense output (every 1^3 / 3^3 stride-1 forward and data gradient away from the last M tile): rows are
+    // m0 + trow, so the stores (and the addend / mask loads) are buffer accesses with a fixed per-thread offset and the row
+    // group in the scalar offset -- no per-row index or 64-bit address arithmetic (exact-fp32 kernels pay every vector
+    // instruction in matrix-pipe time; the K = 64 layers spent ~15 % of their time in this epilogue).
+    const bool fast = !IOH && dense_out && vec_ok && m0 + BM <= g.M && n0 + BN <= g.Nout;
+    const long tile_el = m0 * g.Nout + n0;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)Y + tile_el), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((addend ? (const float*)addend : (const float*)Y) + tile_el), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((amask ? amask : (const unsigned char*)Y) + (tile_el >> 2)), 0, 0x80000000u, 0x00020000);
+    constexpr int RPK = CT / Q;  // staging rows per round of 256 threads
+    const int r_l = tid / Q, q_l = tid % Q;
+    const unsigned vo = (unsigned)((r_l * g.Nout + 4 * q_l) * 4);
+    float4 bv = make_float4(0, 0, 0, 0);
+    if (fast && bias) bv = *(const float4*)(bias + n0 + 4 * q_l);
 #pragma unroll
     for (int h = 0; h < C::TM; ++h) {
       __syncthreads();
@@ -636,6 +652,30 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         for (int j = 0; j < C::TN; ++j) smem[rl * LDO + wn * C::TN * 32 + j * 32 + (lane & 31)] = acc[h][j][r];
       }
       __syncthreads();
+      if (fast) {
+#pragma unroll
+        for (int k2 = 0; k2 < (64 * Q) / CT; ++k2) {
+          const int rowc = k2 * RPK;                                             // staging row = r_l + rowc
+          const int trow_c = (rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31);  // tile row = r_l + trow_c (RPK divides 32)
+          const unsigned so = (unsigned)(trow_c * g.Nout * 4);
+          float4 v = *(const float4*)(smem + (r_l + rowc) * LDO + 4 * q_l);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          if (addend) {
+            float4 av = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, vo, so, 0));
+            if (amask) {
+              const unsigned mk = __builtin_amdgcn_raw_buffer_load_b8(mrs, vo >> 4, so >> 4, 0);
+              av.x = (mk & 1u) ? av.x : 0.f;
+              av.y = (mk & 2u) ? av.y : 0.f;
+              av.z = (mk & 4u) ? av.z : 0.f;
+              av.w = (mk & 8u) ? av.w : 0.f;
+            }
+            v.x += av.x; v.y += av.y; v.z += av.z; v.w += av.w;
+          }
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vo, so, 0);
+        }
+        continue;
+      }
       if constexpr (IOH) {
         // bf16 output (and addend): 8 channels = 16 bytes per lane (the memory-bound 1^3 layers spend their time here)
         if (g.yh && (g.Nout & 7) == 0 && (!addend || g.ah)) {

@@ -10,10 +10,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 template <int V>
 __global__ __launch_bounds__(256) void k(float* out, int iters, int lds_floats_dummy, const float* __restrict__ src, long src_mask) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 256 * 33];
-  __shared__ __attribute__((aligned(16))) float dma[2 * 256 * 32];  // LDS-DMA landing zone (two dense tiles)
+  constexpr int SMEM_ROWS = (V == 10 || V == 12) ? 512 : 256;   // two buffers only where a variant uses them: occupancy as in the real kernel
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_ROWS * 36];
+  __shared__ __attribute__((aligned(16))) float dma[(V == 7 || V == 9) ? 2 * 256 * 32 : 64];  // LDS-DMA landing zone (two dense tiles)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < 2 * 256 * 33; i += 256) smem[i] = (float)(i % 7) * 0.25f;
+  for (int i = tid; i < SMEM_ROWS * 36; i += 256) smem[i] = (float)(i % 7) * 0.25f;
   __syncthreads();
   f32x16 acc[2][2];
   for (int a = 0; a < 2; ++a)
@@ -26,7 +27,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int lds_floats_d
   float4 st[8];
   for (int i = 0; i < 8; ++i) st[i] = make_float4(0.1f * i, 0.2f, 0.3f, 0.4f);
   long goff = ((long)blockIdx.x * 977 + r0) * 64 + kq * 4;
+  // V8 / V9 (round 3): the same eight 16-byte loads per thread and tile as BUFFER loads whose per-thread offset is fixed and
+  // whose tile displacement is a scalar -- no vector instruction per load.  V8: into registers (+ the 32 LDS writes of V3);
+  // V9: straight into LDS (LDS-DMA), no writes at all.  (V4 / V7 spend ~6 vector-ALU instructions per load on `goff`.)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x80000000u, 0x00020000);
+  const unsigned voff = (unsigned)(((blockIdx.x * 977 + r0) * 64 + kq * 4) * 4) & 0x3fffffu;
   for (int it = 0; it < iters; ++it) {
+    if (V == 8 || V == 9) {
+      const unsigned so = (unsigned)(((it * 2053) & 0x3ff) << 12) & (unsigned)(src_mask * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (V == 8)
+          st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so + i * 4096, 0));
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dma + ((it & 1) * 8192 + (wave * 8 + i) * 256)), 16,
+                                                   voff, so + i * 4096, 0, 0);
+      }
+    }
     if (V == 7) {
       // 8 LDS-DMA pieces per wave per tile: lane i of piece p lands at dma + (wave*8 + p) * 256 floats + 4 i
 #pragma unroll
@@ -39,6 +56,64 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int lds_floats_d
 #pragma unroll
       for (int i = 0; i < 8; ++i) st[i] = *(const float4*)(src + ((goff + (long)i * 32 * 64) & src_mask));
       goff += 8 * 32 * 64 + 64 * 13;
+    }
+    if (V >= 10) {
+      // V10: two LDS buffers (pitch 33, dword reads / writes), ONE barrier per tile; V11: one buffer, 16-byte fragment reads and
+      // staging writes (pitch 36, K permuted: lane half h owns K quads 2s + h), two barriers; V12: both
+      constexpr bool DB = V == 10 || V == 12, W4 = V == 11 || V == 12;
+      constexpr int LP = W4 ? 36 : 33;
+      const float* rb = smem + (DB ? (it & 1) * 256 * LP : 0);
+      float* wb = smem + (DB ? ((it + 1) & 1) * 256 * LP : 0);
+      const unsigned so = (unsigned)(((it * 2053) & 0x3ff) << 12) & (unsigned)(src_mask * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so + i * 4096, 0));
+      if (W4) {
+        const float* a4 = rb + ((wave >> 1) * 64 + (lane & 31)) * LP + 4 * (lane >> 5);
+        const float* b4 = rb + 128 * LP + ((wave & 1) * 64 + (lane & 31)) * LP + 4 * (lane >> 5);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float4 qa0 = *(const float4*)(a4 + 8 * s4), qa1 = *(const float4*)(a4 + 32 * LP + 8 * s4);
+          const float4 qb0 = *(const float4*)(b4 + 8 * s4), qb1 = *(const float4*)(b4 + 32 * LP + 8 * s4);
+          const float xa0[4] = {qa0.x, qa0.y, qa0.z, qa0.w}, xa1[4] = {qa1.x, qa1.y, qa1.z, qa1.w};
+          const float xb0[4] = {qb0.x, qb0.y, qb0.z, qb0.w}, xb1[4] = {qb1.x, qb1.y, qb1.z, qb1.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[e], xb0[e], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[e], xb1[e], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[e], xb0[e], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[e], xb1[e], acc[1][1], 0, 0, 0);
+          }
+        }
+      } else {
+        const float* a1 = rb + ((wave >> 1) * 64 + (lane & 31)) * LP + (lane >> 5);
+        const float* b1 = rb + 128 * LP + ((wave & 1) * 64 + (lane & 31)) * LP + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          fa[0] = a1[2 * kk];
+          fa[1] = a1[32 * LP + 2 * kk];
+          fb[0] = b1[2 * kk];
+          fb[1] = b1[32 * LP + 2 * kk];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (!DB) __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float* d = wb + (r0 + 32 * i) * LP + kq * 4;
+        if (W4) {
+          *(float4*)d = st[i];
+        } else {
+          d[0] = st[i].x;
+          d[1] = st[i].y;
+          d[2] = st[i].z;
+          d[3] = st[i].w;
+        }
+      }
+      __syncthreads();
+      continue;
     }
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
@@ -67,7 +142,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int lds_floats_d
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (V >= 2) __syncthreads();
-    if (V >= 3 && V != 7) {
+    if (V >= 3 && V != 7 && V != 9) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float* d = smem + (r0 + 32 * i) * 33 + kq * 4;
@@ -79,7 +154,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int lds_floats_d
       __syncthreads();
     }
   }
-  float s = dma[tid];
+  float s = dma[tid & 63];
   for (int a = 0; a < 2; ++a)
     for (int b = 0; b < 2; ++b)
       for (int r = 0; r < 16; ++r) s += acc[a][b][r];
@@ -120,6 +195,11 @@ int main() {
     run<7>("  LDS-DMA: 8 x 1 KiB pieces / wave / tile (L2)", 256 * bpc, iters, d, src, (1l << 22) - 1);
     run<5>("  loads spread: 1 float4 per 2 k-steps (L2)", 256 * bpc, iters, d, src, (1l << 22) - 1);
     run<6>("  loads as 32 dword loads over 8 k-steps (L2)", 256 * bpc, iters, d, src, (1l << 22) - 1);
+    run<8>("  BUFFER loads, scalar tile offset -> regs (L2)", 256 * bpc, iters, d, src, (1l << 22) - 1);
+    run<9>("  BUFFER loads -> LDS (DMA), scalar offset (L2)", 256 * bpc, iters, d, src, (1l << 22) - 1);
+    run<10>("  BUFFER -> regs, TWO LDS buffers, 1 barrier", 256 * bpc, iters, d, src, (1l << 22) - 1);
+    run<11>("  BUFFER -> regs, 16-byte LDS reads+writes", 256 * bpc, iters, d, src, (1l << 22) - 1);
+    run<12>("  BUFFER -> regs, two buffers + 16-byte LDS", 256 * bpc, iters, d, src, (1l << 22) - 1);
   }
   return 0;
 }
