@@ -166,6 +166,56 @@ struct PassGeom {
 // Forward pass along one axis: L samples in, 2L (parity q, position) out.
 // REAL_IN: input is the real batch (B,T,N,N); samples 2p / 2p+1 become re / im and the
 // band operator (t-resampling, fused g^k scaling) is applied on the way in.
+// Band operator (the sqrt-time resampling, a sparse row-compressed L x L matrix with ~2 entries per row, <= 32 in a few rows
+// near t = 0) applied to the L x WT tile in LDS, for L >= NT: a thread owns whole rows n = tid + NT j (all WT complex columns),
+// so a row's table entries are fetched ONCE (not once per column), the offsets of all its rows first, then the first two
+// entries of every row speculatively (clamped index, zero weight past the row's end): two dependent global round trips per
+// thread instead of one per entry and element; rows with more than two entries finish in a short loop.  The LDS reads are
+// whole rows (WT x 8 bytes contiguous).
+template <int L, int WT>
+__device__ __forceinline__ void band_rows(const float2* __restrict__ s, const int32_t* __restrict__ boff,
+                                          const int32_t* __restrict__ bidx, const float* __restrict__ bval, int tid,
+                                          float2 (&u)[(L / NT) * WT]) {
+  constexpr int RPT = L / NT;
+  const int nnz = boff[L];
+  int t0[RPT], t1[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    t0[j] = boff[tid + NT * j];
+    t1[j] = boff[tid + NT * j + 1];
+  }
+  int bi[RPT][2];
+  float bv[RPT][2];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int t = min(t0[j] + k, nnz - 1);
+      bi[j][k] = bidx[t];
+      bv[j][k] = t0[j] + k < t1[j] ? bval[t] : 0.f;
+    }
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const float2* r0 = s + bi[j][0] * WT;
+    const float2* r1 = s + bi[j][1] * WT;
+#pragma unroll
+    for (int c = 0; c < WT; ++c) {
+      const float2 a = r0[c], b = r1[c];
+      u[j * WT + c] = make_float2(bv[j][0] * a.x + bv[j][1] * b.x, bv[j][0] * a.y + bv[j][1] * b.y);
+    }
+    for (int t = t0[j] + 2; t < t1[j]; ++t) {   // the few long rows
+      const float cf = bval[t];
+      const float2* rr = s + bidx[t] * WT;
+#pragma unroll
+      for (int c = 0; c < WT; ++c) {
+        const float2 v = rr[c];
+        u[j * WT + c].x += cf * v.x;
+        u[j * WT + c].y += cf * v.y;
+      }
+    }
+  }
+}
+
 template <int L, int WT, bool REAL_IN>
 __global__ __launch_bounds__(NT) void k_axis_fwd(const float* __restrict__ xr, const float2* __restrict__ in,
                                                  float2* __restrict__ out, int batch, long vol, PassGeom g,
@@ -198,17 +248,21 @@ __global__ __launch_bounds__(NT) void k_axis_fwd(const float* __restrict__ xr, c
       s[e] = make_float2(x0[gi], has1 ? x1[gi] : 0.0f);
     }
     __syncthreads();
+    if constexpr (L >= NT) {
+      band_rows<L, WT>(s, boff, bidx, bval, tid, u);   // u[j * WT + c] = element (row tid + NT j, column c)
+    } else {
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int e = tid + k * NT, n = e / WT, col = e % WT;
-      float2 acc = make_float2(0.f, 0.f);
-      for (int t = boff[n]; t < boff[n + 1]; ++t) {
-        const float c = bval[t];
-        const float2 v = s[bidx[t] * WT + col];
-        acc.x += c * v.x;
-        acc.y += c * v.y;
+      for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NT, n = e / WT, col = e % WT;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int t = boff[n]; t < boff[n + 1]; ++t) {
+          const float c = bval[t];
+          const float2 v = s[bidx[t] * WT + col];
+          acc.x += c * v.x;
+          acc.y += c * v.y;
+        }
+        u[k] = acc;
       }
-      u[k] = acc;
     }
   } else {
     const float2* ip = in + (long)pair * g.in_pair_stride;
@@ -221,10 +275,20 @@ __global__ __launch_bounds__(NT) void k_axis_fwd(const float* __restrict__ xr, c
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     __syncthreads();
+    if constexpr (REAL_IN && L >= NT) {   // row-owning element order of band_rows
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int e = tid + k * NT, n = e / WT;
-      s[e] = q ? cmul(u[k], shs[n]) : u[k];
+      for (int j = 0; j < L / NT; ++j) {
+        const int n = tid + NT * j;
+        const float2 h = shs[n];
+#pragma unroll
+        for (int c = 0; c < WT; ++c) s[n * WT + c] = q ? cmul(u[j * WT + c], h) : u[j * WT + c];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NT, n = e / WT;
+        s[e] = q ? cmul(u[k], shs[n]) : u[k];
+      }
     }
     __syncthreads();
     fft_dif<L, WT, WT>(s, stw, tid);
@@ -282,6 +346,21 @@ __global__ __launch_bounds__(NT) void k_axis_inv(const float2* __restrict__ in, 
     float* y0 = yr + (long)(2 * pair) * vol;
     const bool has1 = (2 * pair + 1) < batch;
     float* y1 = yr + (long)(2 * pair + 1) * vol;
+    if constexpr (L >= NT) {   // whole rows per thread (band_rows); WT consecutive floats per volume and row
+      float2 o[(L / NT) * WT];
+      band_rows<L, WT>(s, boff, bidx, bval, tid, o);
+#pragma unroll
+      for (int j = 0; j < L / NT; ++j) {
+        const long gi = obase + (long)(tid + NT * j) * g.out_axis_stride;
+#pragma unroll
+        for (int c = 0; c < WT; c += 4) {
+          *reinterpret_cast<float4*>(y0 + gi + c) = make_float4(o[j * WT + c].x, o[j * WT + c + 1].x, o[j * WT + c + 2].x, o[j * WT + c + 3].x);
+          if (has1)
+            *reinterpret_cast<float4*>(y1 + gi + c) = make_float4(o[j * WT + c].y, o[j * WT + c + 1].y, o[j * WT + c + 2].y, o[j * WT + c + 3].y);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const int e = tid + k * NT, n = e / WT, col = e % WT;
@@ -421,26 +500,41 @@ __global__ __launch_bounds__(NT) void k_axis_fwd_t_lone(const float* __restrict_
     s[e] = *reinterpret_cast<const float2*>(x + (long)n * plane + col0 + 2 * col);
   }
   __syncthreads();
+  constexpr bool ROWS = L >= NT;   // a thread owns whole rows (band_rows); shorter transforms keep one element per (row, column)
+  if constexpr (ROWS) {
+    band_rows<L, WT>(s, boff, bidx, bval, tid, u);
+  } else {
 #pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    const int e = tid + k * NT, n = e / WT, col = e % WT;
-    float2 acc = make_float2(0.f, 0.f);
-    for (int t = boff[n]; t < boff[n + 1]; ++t) {
-      const float c = bval[t];
-      const float2 v = s[bidx[t] * WT + col];
-      acc.x += c * v.x;
-      acc.y += c * v.y;
+    for (int k = 0; k < EPT; ++k) {
+      const int e = tid + k * NT, n = e / WT, col = e % WT;
+      float2 acc = make_float2(0.f, 0.f);
+      for (int t = boff[n]; t < boff[n + 1]; ++t) {
+        const float c = bval[t];
+        const float2 v = s[bidx[t] * WT + col];
+        acc.x += c * v.x;
+        acc.y += c * v.y;
+      }
+      u[k] = acc;
     }
-    u[k] = acc;
   }
   const TwFromHalf tw{shs, L};
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     __syncthreads();
+    if constexpr (ROWS) {
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int e = tid + k * NT, n = e / WT;
-      s[e] = q ? cmul(u[k], shs[n]) : u[k];
+      for (int j = 0; j < L / NT; ++j) {
+        const int n = tid + NT * j;
+        const float2 h = shs[n];
+#pragma unroll
+        for (int c = 0; c < WT; ++c) s[n * WT + c] = q ? cmul(u[j * WT + c], h) : u[j * WT + c];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NT, n = e / WT;
+        s[e] = q ? cmul(u[k], shs[n]) : u[k];
+      }
     }
     __syncthreads();
     fft_dif_f<L, WT, WT>(s, tw, tid);
@@ -503,6 +597,18 @@ __global__ __launch_bounds__(NT) void k_axis_inv_t_lone(const float2* __restrict
 #pragma unroll
   for (int k = 0; k < EPT; ++k) s[tid + k * NT] = acc[k];
   __syncthreads();
+  if constexpr (L >= NT) {
+    float2 o[(L / NT) * WT];
+    band_rows<L, WT>(s, boff, bidx, bval, tid, o);
+#pragma unroll
+    for (int j = 0; j < L / NT; ++j) {
+      float* dst = y + (long)(tid + NT * j) * plane + col0;   // 2 WT adjacent real columns of row n
+#pragma unroll
+      for (int c = 0; c < WT; c += 2)
+        *reinterpret_cast<float4*>(dst + 2 * c) = make_float4(o[j * WT + c].x, o[j * WT + c].y, o[j * WT + c + 1].x, o[j * WT + c + 1].y);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int e = tid + k * NT, n = e / WT, col = e % WT;
