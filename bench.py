@@ -264,7 +264,7 @@ def bench_sformer(args, emit=True):
     return line
 
 
-def bench_ingest(args):
+def bench_ingest(args, emit=True):
     """one dataset sample (600 x 256 x 256 RGBE image + 256^3 volume) -> network inputs
     (128^3 transient, 128^3 target) on the device, inputs resident in HBM; the oracle (NumPy restatement of
     utils/nlos_pose_dataloader.py:71-144) timed on the host as the CPU baseline."""
@@ -324,7 +324,9 @@ def bench_ingest(args):
         cpu = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": round(1.0 / cpu, 3), "unit": "samples/s", "cores": 1, "kind": "port",
                                 "sample": "the same single sample, NumPy float32 (decode from expanded RGBE bytes onward)"}
-    print(json.dumps(line), flush=True)
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def bench_highres(args, emit=True):
@@ -736,6 +738,11 @@ def main():
                 line["extra"]["configs4_sformer_fp16"] = {k: sf[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
                                                                              "dtype", "config", "roofline")}
                 note(f"extra: sformer {sf['ms_per_step']:.1f} ms/step")
+                torch.cuda.empty_cache()
+                sub.no_cpu_baseline = True
+                ig = bench_ingest(sub, emit=False)   # one dataset sample -> network inputs on the device
+                line["extra"]["ingest"] = {k: ig[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline")}
+                note(f"extra: ingest {ig['ms_per_step']:.3f} ms/sample")
         if world == 1 and not args.no_cpu_baseline:
             # the box's CPU share for one GPU is 16 cores: more threads than that only oversubscribe
             try:
