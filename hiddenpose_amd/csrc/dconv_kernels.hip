@@ -53,7 +53,14 @@ __global__ __launch_bounds__(256) void k_fold_replicate(const float* __restrict_
 constexpr int WG_TY = 8, WG_TX = 64, WG_PX = 68, WG_PY = WG_TY + 2, WG_PLANE = 4 * WG_PY * WG_PX;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int PADMODE>
+// FOLD (with PADMODE 0, pad 1, flip 1): the data gradient of a REPLICATE-padded convolution in one pass.  The adjoint of
+// "clamp the read position" folds the weight of every tap that pointed outside the volume onto the border voxel's own
+// position, independently per axis: at coordinate 0 the centre weight of that axis gains the weight of index 2 (flipped
+// order), at the last coordinate that of index 0 -- the zero-padded correlation with position-dependent weights on the six
+// faces.  y rows are fixed per thread (weights folded once), z planes per step (centre-plane weights summed in a uniform
+// branch), x ends are two corrections per plane for the lanes that own x = 0 / x = W - 1.  Replaces the correlation on the
+// (D+2)(H+2)(W+2) halo domain + k_fold_replicate (a second pass over a larger volume).
+template <int PADMODE, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g,
                                                            int cin, int cout,
                                                            int D, int H, int W, int tiles_x, int tiles_y, int zchunk,
@@ -897,7 +904,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_f16(const float* __restrict__
 // 3 planes x 3 rows x 6 columns it needs in registers: one new plane = 18 loads (served by L1/L2: neighbouring
 // threads share all but their own four columns) for 108 FMAs; weights are wave-uniform scalars.  Same generic
 // interface as run_dconv (pad 1 forward, pad 2 for the replicate-padding gradient on the halo domain, flipped taps).
-template <int PADMODE>
+// FOLD (with PADMODE 0, pad 1, flip 1): the data gradient of a REPLICATE-padded convolution in one pass.  The adjoint of
+// "clamp the read position" folds the weight of every tap that pointed outside the volume onto the border voxel's own
+// position, independently per axis: at coordinate 0 the centre weight of that axis gains the weight of index 2 (flipped
+// order), at the last coordinate that of index 0 -- the zero-padded correlation with position-dependent weights on the six
+// faces.  y rows are fixed per thread (weights folded once), z planes per step (centre-plane weights summed in a uniform
+// branch), x ends are two corrections per plane for the lanes that own x = 0 / x = W - 1.  Replaces the correlation on the
+// (D+2)(H+2)(W+2) halo domain + k_fold_replicate (a second pass over a larger volume).
+template <int PADMODE, bool FOLD = false>
 __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                     float* __restrict__ y, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
@@ -911,6 +925,19 @@ __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x,
   float wt[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) wt[t] = w[flip ? 26 - t : t];
+  float lo_f = 0.f, hi_f[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float lo = oy == 0 ? wt[dz * 9 + 6 + dx] : 0.f, hi = oy == Ho - 1 ? wt[dz * 9 + dx] : 0.f;
+        wt[dz * 9 + 3 + dx] += lo + hi;
+      }
+    lo_f = ox == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hi_f[i] = ox + i == Wo - 1 ? 1.f : 0.f;
+  }
   const float bv = bias ? bias[0] : 0.f;
   const float* xb = x + (long)b * Di * Hi * Wi;
   // row / column addressing of the 3 x 6 window, fixed for the whole walk
@@ -964,16 +991,46 @@ __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x,
   const bool vec = (Wo & 3) == 0;
   auto emit = [&](int z, const float (&p0)[3][6], const float (&p1)[3][6], const float (&p2)[3][6]) {
     float o[4] = {bv, bv, bv, bv};
+    if constexpr (FOLD) {
+      float wc[9];   // centre-plane weights: the plane that would lie outside folds onto it (z is uniform)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+      for (int t = 0; t < 9; ++t) wc[t] = wt[9 + t] + (z == 0 ? wt[18 + t] : 0.f) + (z == Do - 1 ? wt[t] : 0.f);
+      auto plane = [&](const float (&pp)[3][6], const float* w9) {
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = fmaf(w9[dy * 3 + dx], pp[dy][i + dx], o[i]);
+        // x ends: centre position gains the weight of the tap that pointed outside (index 2 at x = 0, index 0 at x = W - 1)
+        float elo = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) elo = fmaf(w9[dy * 3 + 2], pp[dy][1], elo);
+        o[0] = fmaf(lo_f, elo, o[0]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          o[i] = fmaf(wt[dy * 3 + dx], p0[dy][i + dx], o[i]);
-          o[i] = fmaf(wt[9 + dy * 3 + dx], p1[dy][i + dx], o[i]);
-          o[i] = fmaf(wt[18 + dy * 3 + dx], p2[dy][i + dx], o[i]);
+          if (vec && i < 3) continue;   // rows that are whole quads end in a lane's last output
+          float ehi = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) ehi = fmaf(w9[dy * 3], pp[dy][i + 1], ehi);
+          o[i] = fmaf(hi_f[i], ehi, o[i]);
         }
+      };
+      plane(p0, wt);
+      plane(p1, wc);
+      plane(p2, wt + 18);
+    } else {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = fmaf(wt[dy * 3 + dx], p0[dy][i + dx], o[i]);
+            o[i] = fmaf(wt[9 + dy * 3 + dx], p1[dy][i + dx], o[i]);
+            o[i] = fmaf(wt[18 + dy * 3 + dx], p2[dy][i + dx], o[i]);
+          }
+    }
     const long ob = (((long)b * Do + z) * Ho + oy) * Wo + ox;
     if (!live) return;
     if (vec) {
@@ -1132,6 +1189,17 @@ extern "C" int hp_dconv3_backward_data(const float* gy, const float* w, float* g
   if (!replicate_pad) {
     HP_PROF("dconv3_dgrad", st);
     return run_dconv(gy, w, nullptr, nullptr, gx, nullptr, 1.0f, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st);
+  }
+  if (cin == 1 && cout == 1 && !use_mfma_c1()) {
+    // single-channel layers (FeatureExtraction): the replicate fold inside the stencil kernel, one pass over (D, H, W)
+    HP_PROF("dconv3_dgrad", st);
+    static const int zc_env = getenv("HP_STENCIL_ZC") ? atoi(getenv("HP_STENCIL_ZC")) : 0;
+    const int zc = zc_env > 0 ? zc_env : (D >= 256 ? 64 : std::max(8, (D + 3) / 4));
+    dim3 g1((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + zc - 1) / zc)));
+    hipLaunchKernelGGL((k_stencil_c1<0, true>), g1, dim3(256), 0, st, gy, w, (const float*)nullptr, (const float*)nullptr, gx, D, H, W, D, H,
+                       W, 1, 1, zc, 1.0f);
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
   }
   HP_REQUIRE(workspace, "hp_dconv3_backward_data: replicate padding needs the workspace");
   float* dpad = (float*)workspace;

@@ -1,0 +1,10 @@
+set -x
+mkdir -p gpurun_out/r3
+export PYTHONUNBUFFERED=1
+timeout -k 10 900 python -m pytest tests/test_dconv_gpu.py tests/test_stages_gpu.py tests/test_highres_gpu.py tests/test_nlospose_gpu.py -q -m gpu -x > gpurun_out/r3/gpu_tests_24.log 2>&1 ; tail -3 gpurun_out/r3/gpu_tests_24.log
+timeout -k 10 300 python bench.py --workload highres --steps 5 --warmup 2 > gpurun_out/r3/bench_highres_24.json 2> gpurun_out/r3/bench_highres_24.err
+python3 - <<'PY'
+import json
+l=json.loads(open("gpurun_out/r3/bench_highres_24.json").read().strip().splitlines()[-1])
+print(l["ms_per_step"], {k:v for k,v in l["hip_kernel_ms_per_step"].items() if k.startswith("dconv")})
+PY
