@@ -329,7 +329,7 @@ def bench_ingest(args, emit=True):
     return line
 
 
-def bench_highres(args, emit=True):
+def bench_highres(args, emit=True, also_bf16=False):
     """BASELINE config 4: 256x256x1024 transient, FeatureExtraction -> LCT -> normalize -> UNet3d only
     (forward + backward w.r.t. the FE / UNet parameters), batch 1, HBM-bandwidth roofline of the LCT."""
     from hiddenpose_amd import _lib
@@ -350,6 +350,11 @@ def bench_highres(args, emit=True):
     fp.method.plan_for(meas.device)
     print(f"[bench] constants + plan for T={T} N={N}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
 
+    # --conv-precision bf16 / bf16s: the multi-channel 3^3 convolutions on the bf16 matrix cores (forward and data gradient;
+    # fp32 tensors, fp32 accumulation, fp32 LCT / norms / weight gradients), as in BASELINE configs[2]
+    dconv_bf16 = getattr(args, "conv_precision", "fp32") in ("bf16", "bf16s")
+    ops.set_dconv_precision("bf16" if dconv_bf16 else "fp32")
+
     def step():
         f = ops.normalize_feature(fp(fe(meas), [0] * B, [T] * B))
         r = un(f)
@@ -366,6 +371,7 @@ def bench_highres(args, emit=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.profile_enable(False)
+    ops.set_dconv_precision("fp32")
     prof = _lib.profile_read()
     V = T * N * N
     lct_ms = sum(v[1] for k, v in prof.items() if k.startswith("lct_"))
@@ -380,7 +386,8 @@ def bench_highres(args, emit=True):
         "metric": "samples/sec (256x256x1024 meas) FE+LCT+normalize+UNet fwd+bwd", "value": round(B * args.steps / dt, 3),
         "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 tensors and LCT; multi-channel 3^3 convolutions fwd / data gradient with bf16 operands (MFMA 4x4x4), f32 accumulation"
+                 if dconv_bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"FeatureExtraction+LCT+normalize_feature+UNet3d fwd+bwd, {N}x{N}x{T}, batch {B}"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items()) if v[1] / args.steps > 0.05},
         "roofline": {"kernel": "lct (5 passes, forward or adjoint)", "bound": "hbm", "achieved": round(ach, 1) if ach else None,
@@ -391,7 +398,27 @@ def bench_highres(args, emit=True):
                      "ms_per_direction": round(lct_ms / lct_calls, 3) if lct_ms else None},
         "thin_channel_convolutions": {"ms_per_step": round(conv_ms, 3), "algorithmic_gflop_per_step": conv_gflop,
                                       "achieved_tflops": round(conv_gflop / conv_ms, 1) if conv_ms else None,
-                                      "peak_tflops": MFMA_F32_PEAK_TFLOPS}}
+                                      "peak_tflops": MFMA_F32_PEAK_TFLOPS if not dconv_bf16 else None}}
+    if also_bf16 and not dconv_bf16:
+        # the same step with the multi-channel convolutions' forward / data gradient on the bf16 matrix cores (configs[2] arithmetic)
+        ops.set_dconv_precision("bf16")
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        ops.set_dconv_precision("fp32")
+        pb = _lib.profile_read()
+        line["bf16_thin_channel"] = {
+            "ms_per_step": round(1e3 * dtb / args.steps, 3), "value": round(B * args.steps / dtb, 3), "unit": "samples/s",
+            "dtype": "f32 tensors and LCT; multi-channel 3^3 convolutions fwd / data gradient with bf16 operands (MFMA 4x4x4)",
+            "thin_channel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(pb.items()) if k.startswith("dconv3_")}}
     if emit:
         print(json.dumps(line), flush=True)
     return line
@@ -728,9 +755,10 @@ def main():
                 torch.cuda.empty_cache()
                 sub = argparse.Namespace(**vars(args))
                 sub.steps, sub.warmup, sub.batch = 3, 1, 0
-                hr = bench_highres(sub, emit=False)
+                hr = bench_highres(sub, emit=False, also_bf16=True)
                 line["extra"]["configs3_highres"] = {k: hr[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup",
-                                                                        "config", "roofline", "thin_channel_convolutions")}
+                                                                        "config", "roofline", "thin_channel_convolutions",
+                                                                        "bf16_thin_channel")}
                 note(f"extra: highres {hr['ms_per_step']:.1f} ms/step")
                 torch.cuda.empty_cache()
                 sub.conv_precision, sub.attention = "bf16", "fp16"

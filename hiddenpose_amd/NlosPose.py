@@ -39,14 +39,20 @@ class NlosPose(nn.Module):
                                                       dev=cfg.DEVICE)
         self.autoencoder = UNet3d(1, 4)
         self.pose_net = get_pose_net_50(getattr(m, "CONV_PRECISION", "fp32"))
+        dp = getattr(m, "DCONV_PRECISION", "auto")
+        self.dconv_precision = ("bf16" if getattr(m, "CONV_PRECISION", "fp32") == "bf16s" else "fp32") if dp == "auto" else dp
 
     def forward(self, meas):
         n = meas.shape[0]
         window = ([self.time_begin] * n, [self.time_end] * n)
-        feature = K.normalize_feature(self.feature_propagation(self.feature_extraction(meas), *window))
-        if isinstance(self.autoencoder, UNet3d) and self.autoencoder.in_channels == 1:
-            refine_feature, summed = self.autoencoder.forward_and_sum(feature)   # `feature + refine` in the same pass
-        else:
-            refine_feature = self.autoencoder(feature)
-            summed = K.add(feature, refine_feature)
+        prev = K.set_dconv_precision(self.dconv_precision)  # the backward of every node uses what its forward ran with
+        try:
+            feature = K.normalize_feature(self.feature_propagation(self.feature_extraction(meas), *window))
+            if isinstance(self.autoencoder, UNet3d) and self.autoencoder.in_channels == 1:
+                refine_feature, summed = self.autoencoder.forward_and_sum(feature)   # `feature + refine` in the same pass
+            else:
+                refine_feature = self.autoencoder(feature)
+                summed = K.add(feature, refine_feature)
+        finally:
+            K.set_dconv_precision(prev)
         return self.pose_net(summed), refine_feature

@@ -70,6 +70,10 @@ def get_cfg_defaults() -> CfgNode:
         # not a reference key: arithmetic of the regressor's convolution GEMMs, "fp32" (default, exact) or
         # "bf16" (bf16 operands / fp32 accumulation; LCT, U-Net, norms and losses stay fp32)
         CONV_PRECISION="fp32",
+        # not a reference key: arithmetic of the thin-channel 3^3 convolutions of the U-Net / FeatureExtraction (layers with
+        # more than one channel): "fp32" (exact) or "bf16" (bf16 operands on v_mfma_f32_4x4x4_16b_bf16, fp32 accumulation,
+        # fp32 tensors); "auto" = bf16 exactly when CONV_PRECISION is "bf16s" (BASELINE configs[2]: bf16 with fp32 LCT)
+        DCONV_PRECISION="auto",
     )
     c.DATASET = CfgNode(NAME="NlosPoseDataset", NUM_JOINTS=24, HEATMAP_SIZE=[64, 64, 64], VOL_SIZE=[256, 256, 256],
                         DAWNSAMPLE_CNT=1, PHASE="train", TRAIN_PATH="", TEST_PATH="")

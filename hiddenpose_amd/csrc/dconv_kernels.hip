@@ -448,6 +448,10 @@ __global__ __launch_bounds__(1024) void k_dconv3_wgrad_reduce(const float* __res
 }
 
 
+struct EpiVals {
+  float a[2][4], r[2][4];  // [row of the wave][output channel]: addend (bias or partial sum), residual
+};
+
 // Forward / data-gradient 3x3x3 convolution on the same 4x4x1 matrix-core instruction.  Roles: row i = output
 // channel co0 + i (lane 4b+i supplies the weight, identical in all 16 blocks), column j = voxel 4b + j of a 64-voxel
 // x-run (lane l supplies x[l + tap]), K = one (input channel, tap) per instruction:
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_dconv3_wgrad_reduce(const float* __res
 // planes of a 4-channel chunk in the same 4-slot LDS ring as the weight gradient; the 27 weights of the current
 // input channel sit in registers (7 broadcast ds_read_b128 per channel and plane).  More than 4 input channels:
 // the chunks are separate z sweeps and every sweep after the first adds into y.
-template <int PADMODE>
+template <int PADMODE, int S>
 __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int cin,
                                                          int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad,
@@ -484,6 +488,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
   const long ybase = ((long)b * cout + cog * 4) * ocs;   // this workgroup's 4 output channels: offsets within them fit 31 bits
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias && cog * 4 + i < cout ? bias[cog * 4 + i] : 0.f;
 
   for (int c0 = 0; c0 < cin; c0 += 4) {
     const int nci = min(4, cin - c0);
@@ -554,8 +561,29 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     }
     __syncthreads();
     const int lbase = (2 * wave) * WG_PX + lane;
+    // What the epilogue of a step adds to its accumulators -- the bias (first sweep) or the partial sum already in y (later
+    // sweeps), and the residual (last sweep) -- is REQUESTED before the step's plane prefetch and used after its multiply
+    // phase: one memory round trip hidden behind the MFMAs instead of eight exposed ones (a load per output row and channel,
+    // each waited for on the spot), and the wait for it leaves the younger plane prefetches in flight.
+    const bool last = c0 + 4 >= cin;
+    auto epi_load = [&](int z, EpiVals& ev) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = y0 + 2 * wv + r;   // scalar
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ev.a[r][i] = c0 == 0 ? bv[i] : 0.f;
+          ev.r[r][i] = 0.f;
+          if (oy < Ho && cog * 4 + i < cout) {
+            const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
+            if (c0 != 0) ev.a[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, xoff, so, 0));
+            if (last && res) ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, xoff, so, 0));
+          }
+        }
+      }
+    };
     // one output plane: multiply against the three ring planes, store
-    auto compute = [&](int z) {
+    auto compute = [&](int z, const EpiVals& ev) {
       const float* p0 = ring + ((z - pad) & 3) * WG_PLANE + lbase;
       const float* p1 = ring + ((z - pad + 1) & 3) * WG_PLANE + lbase;
       const float* p2 = ring + ((z - pad + 2) & 3) * WG_PLANE + lbase;
@@ -598,10 +626,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
             const int oc = cog * 4 + i;
             if (oc < cout) {
               const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
-              float v = acc[r][i] + (c0 == 0 ? (bias ? bias[oc] : 0.f)
-                                             : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, xoff, so, 0)));
-              if (c0 + 4 >= cin) {  // last channel chunk: the sum is complete -> residual, activation, statistics
-                if (res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, xoff, so, 0));
+              float v = acc[r][i] + ev.a[r][i];
+              if (last) {  // last channel chunk: the sum is complete -> residual, activation, statistics
+                if (res) v += ev.r[r][i];
                 if (slope != 1.0f) v = v > 0.f ? v : v * slope;
                 const float vs = xin ? v : 0.f;   // lanes beyond the row do not count
                 st1[i] += vs;
@@ -615,25 +642,271 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     };
     // Two planes are in flight at any time (register sets A / B): with a single plane the kernel was bound by the bytes it
     // kept outstanding (~22 KB per CU against a ~2 us loaded memory latency), not by the matrix pipe or LDS.
-    float nA[SK], nB[SK];
-    if (zb + 1 < ze) stage_load(zb - pad + 3, nA);
-    for (int z = zb; z < ze; z += 2) {
-      if (z + 2 < ze) stage_load(z - pad + 4, nB);
-      __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the multiply phase (the scheduler would sink it)
-      compute(z);
-      if (z + 1 < ze) stage_store(z - pad + 3, nA);  // the slot held plane z - pad - 1, last read one barrier ago
-      __syncthreads();
-      if (z + 1 < ze) {
-        if (z + 3 < ze) stage_load(z - pad + 5, nA);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(z + 1);
-        if (z + 2 < ze) stage_store(z - pad + 4, nB);
-        __syncthreads();
+    // S register sets rotate: the plane parked after step z (ring slot of plane z - pad - 1, last read one barrier ago) was
+    // requested S - 1 steps earlier, so S - 1 planes are in flight per workgroup at any time
+    float nr[S][SK];
+#pragma unroll
+    for (int i = 0; i < S - 1; ++i)
+      if (zb + i + 1 < ze) stage_load(zb + i - pad + 3, nr[i]);
+    for (int z = zb; z < ze; z += S) {
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int zz = z + s_;
+        if (zz < ze) {  // workgroup-uniform
+          EpiVals ev;
+          epi_load(zz, ev);
+          if (zz + S < ze) stage_load(zz + S - 1 - pad + 3, nr[(s_ + S - 1) % S]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+          compute(zz, ev);
+          if (zz + 1 < ze) stage_store(zz - pad + 3, nr[s_]);
+          __syncthreads();
+        }
       }
     }
   }
   if (stats) {
     // per output channel of this group: all 64 lanes of the four waves hold partial sums
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = st1[i], q = st2[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+      }
+      if (lane == 0) {
+        sred[wave][i] = a;
+        sred[wave][4 + i] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 8) {
+      const int co = cog * 4 + (tid & 3);
+      if (co < cout) {
+        const float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+        atomicAdd(stats + ((long)b * cout + co) * 2 + (tid >> 2), (double)v);
+      }
+    }
+  }
+}
+
+
+// bf16-operand variant of the kernel above (HP_PRECISION_BF16: BASELINE configs[2], "bf16 with fp32 LCT"): tensors stay
+// planar fp32 in HBM, operands are rounded to bf16 (nearest even) on their way into LDS, accumulation is fp32.
+// v_mfma_f32_4x4x4_16b_bf16 takes FOUR input channels per instruction (K = 4) where the fp32 4x4x1 takes one:
+//     D_b[i][j] += sum_{k<4} w[co0+i][c0+k][tap] * x[c0+k][v_{4b+j} + tap]
+// so the ring keeps the planes channel-interleaved -- one 8-byte element (4 bf16 channels) per voxel cell -- and a shifted
+// operand is ONE ds_read_b64 (64 consecutive lanes = 512 contiguous bytes: conflict-free) per 1024 MACs: a quarter of the
+// matrix-core and LDS instructions of the exact kernel.  NQ = channel quads per sweep (4 or 8 input channels; the 8-channel
+// ring has the footprint of the fp32 kernel's 4-channel one, so an 8 -> 4 layer is ONE sweep and y is written once); the
+// 27 * NQ weight operands of a sweep live in registers.  Roles, tiling, z walk and epilogue are those of k_dconv3_mfma.
+using dbf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using dbf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using ds16x4 = __attribute__((ext_vector_type(4))) short;
+using df32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ ds16x4 pack_bf16x4(float a, float b, float c, float d) {
+  const dbf16x2 lo = __builtin_convertvector((df32x2){a, b}, dbf16x2);
+  const dbf16x2 hi = __builtin_convertvector((df32x2){c, d}, dbf16x2);
+  return __builtin_bit_cast(ds16x4, (dbf16x4){lo[0], lo[1], hi[0], hi[1]});
+}
+
+template <int PADMODE, int NQ, int S>
+__global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int cin,
+                                                         int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad,
+                                                         long wsco, long wsci, int flip, int tiles_x, int tiles_y, int zchunk,
+                                                         const float* __restrict__ res, double* __restrict__ stats, float slope) {
+  constexpr int CELLS = WG_PY * WG_PX;   // voxel cells of a staged plane (10 rows x 68)
+  constexpr int SLOT = NQ * CELLS;       // 8-byte elements per ring slot
+  constexpr int SKC = (CELLS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) ds16x4 ring[4 * SLOT];
+  __shared__ __attribute__((aligned(16))) ds16x4 wl[NQ * 4 * 28];  // [quad][co][tap]
+  __shared__ float sred[4][8];
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 3;
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y, cog = blockIdx.z;
+  const int x0 = bx * WG_TX, y0 = by * WG_TY;
+  const int zb = bz * zchunk, ze = min(Do, zb + zchunk);
+  const long ics = (long)Di * Hi * Wi, ocs = (long)Do * Ho * Wo;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const bool xin = x0 + lane < Wo;
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned xoff = xin ? (unsigned)((x0 + lane) * 4) : OOB;
+  const long ybase = ((long)b * cout + cog * 4) * ocs;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, OOB, 0x00020000);
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias && cog * 4 + i < cout ? bias[cog * 4 + i] : 0.f;
+
+  for (int c0 = 0; c0 < cin; c0 += 4 * NQ) {
+    const int nci = min(4 * NQ, cin - c0);
+    __syncthreads();  // previous sweep: ring and weight image are free
+    for (int e = tid; e < NQ * 4 * 28; e += 256) {
+      const int tap = e % 28, co = (e / 28) & 3, q = e / (28 * 4);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tap < 27 && cog * 4 + co < cout) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * q + k < nci) v[k] = w[(long)(cog * 4 + co) * wsco + (long)(c0 + 4 * q + k) * wsci + (flip ? 26 - tap : tap)];
+      }
+      wl[e] = pack_bf16x4(v[0], v[1], v[2], v[3]);
+    }
+    // one descriptor per channel quad (a quad's four planes stay inside the 2 GB a descriptor spans); the per-thread cell
+    // offsets are fixed for the sweep, channel and plane go into the scalar offset
+    __amdgpu_buffer_rsrc_t xrs[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      xrs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ((long)b * cin + min(c0 + 4 * q, cin - 1)) * ics), 0, OOB, 0x00020000);
+    unsigned soff[SKC];
+#pragma unroll
+    for (int k = 0; k < SKC; ++k) {
+      const int e = tid + 256 * k;
+      const int ly = e / WG_PX, lx = e - ly * WG_PX;
+      int yy = y0 + ly - pad, xx = x0 + lx - pad;
+      bool ok = e < CELLS && lx < 66;
+      if (PADMODE == 1) {
+        yy = min(max(yy, 0), Hi - 1);
+        xx = min(max(xx, 0), Wi - 1);
+      } else {
+        ok = ok && (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
+      }
+      soff[k] = ok ? (unsigned)(((long)yy * Wi + xx) * 4) : OOB;
+    }
+    auto stage_load = [&](int zin, float (&v)[SKC][4 * NQ]) {
+      int zz = zin;
+      bool zok = (unsigned)zz < (unsigned)Di;
+      if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
+#pragma unroll
+      for (int c = 0; c < 4 * NQ; ++c) {
+        if (zok && c < nci) {  // workgroup-uniform
+          const unsigned zs = (unsigned)(((long)(c & 3) * ics + (long)zz * Hi * Wi) * 4);
+#pragma unroll
+          for (int k = 0; k < SKC; ++k)
+            v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs[c >> 2], soff[k], zs, 0));
+        } else {
+#pragma unroll
+          for (int k = 0; k < SKC; ++k) v[k][c] = 0.f;
+        }
+      }
+    };
+    auto stage_store = [&](int zin, const float (&v)[SKC][4 * NQ]) {
+      ds16x4* dst = ring + (zin & 3) * SLOT + tid;
+#pragma unroll
+      for (int k = 0; k < SKC; ++k)
+        if (tid + 256 * k < CELLS) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) dst[q * CELLS + 256 * k] = pack_bf16x4(v[k][4 * q], v[k][4 * q + 1], v[k][4 * q + 2], v[k][4 * q + 3]);
+        }
+    };
+    auto stage = [&](int zin) {
+      float v[SKC][4 * NQ];
+      stage_load(zin, v);
+      stage_store(zin, v);
+    };
+    if (zb < ze) {
+      stage(zb - pad);
+      stage(zb - pad + 1);
+      stage(zb - pad + 2);
+    }
+    __syncthreads();
+    // the sweep's weight operands: lane 4b+i supplies output channel i
+    ds16x4 wr[NQ][27];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int t = 0; t < 27; ++t) wr[q][t] = wl[(q * 4 + sub) * 28 + t];
+    const int lbase = (2 * wave) * WG_PX + lane;
+    // What the epilogue of a step adds to its accumulators -- the bias (first sweep) or the partial sum already in y (later
+    // sweeps), and the residual (last sweep) -- is REQUESTED before the step's plane prefetch and used after its multiply
+    // phase: one memory round trip hidden behind the MFMAs instead of eight exposed ones (a load per output row and channel,
+    // each waited for on the spot), and the wait for it leaves the younger plane prefetches in flight.
+    const bool last = c0 + 4 * NQ >= cin;
+    auto epi_load = [&](int z, EpiVals& ev) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = y0 + 2 * wv + r;   // scalar
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ev.a[r][i] = c0 == 0 ? bv[i] : 0.f;
+          ev.r[r][i] = 0.f;
+          if (oy < Ho && cog * 4 + i < cout) {
+            const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
+            if (c0 != 0) ev.a[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, xoff, so, 0));
+            if (last && res) ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, xoff, so, 0));
+          }
+        }
+      }
+    };
+    auto compute = [&](int z, const EpiVals& ev) {
+      const ds16x4* p0 = ring + ((z - pad) & 3) * SLOT + lbase;
+      const ds16x4* p1 = ring + ((z - pad + 1) & 3) * SLOT + lbase;
+      const ds16x4* p2 = ring + ((z - pad + 2) & 3) * SLOT + lbase;
+      f32x4 acc[2];
+      acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+          const ds16x4* pl = (dz == 0 ? p0 : dz == 1 ? p1 : p2) + q * CELLS;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int r = 0; r < 2; ++r)
+                acc[r] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wr[q][(dz * 3 + dy) * 3 + dx], pl[(r + dy) * WG_PX + dx], acc[r], 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = y0 + 2 * wv + r;   // scalar
+        if (oy < Ho) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int oc = cog * 4 + i;
+            if (oc < cout) {
+              const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
+              float v = acc[r][i] + ev.a[r][i];
+              if (last) {  // last channel chunk: the sum is complete -> residual, activation, statistics
+                if (res) v += ev.r[r][i];
+                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
+                const float vs = xin ? v : 0.f;
+                st1[i] += vs;
+                st2[i] += vs * vs;
+              }
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, so, 0);
+            }
+          }
+        }
+      }
+    };
+    float nr[S][SKC][4 * NQ];   // S rotating register sets: S - 1 planes in flight (see k_dconv3_mfma)
+#pragma unroll
+    for (int i = 0; i < S - 1; ++i)
+      if (zb + i + 1 < ze) stage_load(zb + i - pad + 3, nr[i]);
+    for (int z = zb; z < ze; z += S) {
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int zz = z + s_;
+        if (zz < ze) {  // workgroup-uniform
+          EpiVals ev;
+          epi_load(zz, ev);
+          if (zz + S < ze) stage_load(zz + S - 1 - pad + 3, nr[(s_ + S - 1) % S]);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(zz, ev);
+          if (zz + 1 < ze) stage_store(zz - pad + 3, nr[s_]);
+          __syncthreads();
+        }
+      }
+    }
+  }
+  if (stats) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float a = st1[i], q = st2[i];
@@ -1094,6 +1367,13 @@ static bool use_mfma_c1() {  // A/B switch: single-channel layers on the matrix-
   }();
   return v;
 }
+static int dconv_sets(int dflt) {  // A/B switch: planes in flight per workgroup + 1 (register sets of the z walk)
+  static const int v = [] {
+    const char* e = getenv("HP_DCONV_SETS");
+    return e ? atoi(e) : 0;
+  }();
+  return v >= 2 && v <= 4 ? v : dflt;
+}
 static bool use_f16_dconv() {
   static const bool v = [] {
     const char* e = getenv("HP_DCONV_16X16");
@@ -1104,7 +1384,7 @@ static bool use_f16_dconv() {
 
 static int run_dconv(const float* x, const float* w, const float* bias, const float* res, float* y, double* stats, float slope,
                      int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
-                     int flip, int padmode, hipStream_t st) {
+                     int flip, int padmode, hipStream_t st, int precision = HP_PRECISION_FP32) {
   const int tiles_x = (Wo + WG_TX - 1) / WG_TX, tiles_y = (Ho + WG_TY - 1) / WG_TY, cog_n = (cout + 3) / 4;
   const long cols = (long)tiles_x * tiles_y * B * cog_n;
   int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (1536 + cols - 1) / cols));
@@ -1123,13 +1403,39 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
     return HP_OK;
   }
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * cout, st));
+  if (precision == HP_PRECISION_BF16) {
+    // 8 input channels per sweep from 8 channels on (same LDS footprint as the exact kernel), 4 below
+#define HP_DBF_LAUNCH(PM, NQ, S)                                                                                            \
+  hipLaunchKernelGGL((k_dconv3_bf16<PM, NQ, S>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, \
+                     wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope)
+#define HP_DBF_SETS(PM, NQ)                                          \
+  do {                                                               \
+    if (sets == 2) HP_DBF_LAUNCH(PM, NQ, 2);                         \
+    else if (sets == 3) HP_DBF_LAUNCH(PM, NQ, 3);                    \
+    else HP_DBF_LAUNCH(PM, NQ, 4);                                   \
+  } while (0)
+    const int sets = dconv_sets(2);
+    if (cin > 4) {
+      if (padmode) HP_DBF_SETS(1, 2); else HP_DBF_SETS(0, 2);
+    } else {
+      if (padmode) HP_DBF_SETS(1, 1); else HP_DBF_SETS(0, 1);
+    }
+#undef HP_DBF_SETS
+#undef HP_DBF_LAUNCH
+    HP_CHECK_HIP(hipGetLastError());
+    return HP_OK;
+  }
   if (!use_f16_dconv()) {
-    if (padmode)
-      hipLaunchKernelGGL((k_dconv3_mfma<1>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
-                         wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope);
-    else
-      hipLaunchKernelGGL((k_dconv3_mfma<0>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco,
-                         wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope);
+#define HP_DMF_LAUNCH(PM, S)                                                                                                \
+  hipLaunchKernelGGL((k_dconv3_mfma<PM, S>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, \
+                     wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope)
+    const int sets = dconv_sets(2);
+    if (padmode) {
+      if (sets == 2) HP_DMF_LAUNCH(1, 2); else if (sets == 3) HP_DMF_LAUNCH(1, 3); else HP_DMF_LAUNCH(1, 4);
+    } else {
+      if (sets == 2) HP_DMF_LAUNCH(0, 2); else if (sets == 3) HP_DMF_LAUNCH(0, 3); else HP_DMF_LAUNCH(0, 4);
+    }
+#undef HP_DMF_LAUNCH
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
@@ -1177,18 +1483,39 @@ extern "C" int hp_dconv3_forward_fused(const float* x, const float* w, const flo
   return run_dconv(x, w, bias, residual, y, stats, slope, B, cin, cout, D, H, W, D, H, W, 1, (long)cin * 27, 27, 0, replicate_pad, st);
 }
 
+extern "C" int hp_dconv3_forward_fused_p(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                         double* stats, int B, int cin, int cout, int D, int H, int W, int replicate_pad,
+                                         float slope, int precision, void* stream) {
+  HP_REQUIRE(x && w && y && B > 0 && cin > 0 && cout > 0, "hp_dconv3_forward_fused_p: bad argument");
+  HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_dconv3_forward_fused_p: precision must be fp32 or bf16");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("dconv3_fwd", st);
+  return run_dconv(x, w, bias, residual, y, stats, slope, B, cin, cout, D, H, W, D, H, W, 1, (long)cin * 27, 27, 0, replicate_pad, st,
+                   cin == 1 && cout == 1 ? HP_PRECISION_FP32 : precision);
+}
+
 extern "C" size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad) {
   return replicate_pad ? sizeof(float) * (size_t)B * cin * (D + 2) * (H + 2) * (W + 2) : 0;
 }
 
+extern "C" int hp_dconv3_backward_data_p(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H,
+                                         int W, int replicate_pad, int precision, void* workspace, void* stream);
+
 extern "C" int hp_dconv3_backward_data(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H,
                                        int W, int replicate_pad, void* workspace, void* stream) {
+  return hp_dconv3_backward_data_p(gy, w, gx, B, cin, cout, D, H, W, replicate_pad, HP_PRECISION_FP32, workspace, stream);
+}
+
+extern "C" int hp_dconv3_backward_data_p(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H,
+                                         int W, int replicate_pad, int precision, void* workspace, void* stream) {
   HP_REQUIRE(gy && w && gx && B > 0, "hp_dconv3_backward_data: bad argument");
+  HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_dconv3_backward_data_p: precision must be fp32 or bf16");
+  if (cin == 1 && cout == 1) precision = HP_PRECISION_FP32;  // single-channel layers stay on the exact stencil kernel
   hipStream_t st = (hipStream_t)stream;
   // gx[ci] = sum_co corr(gy[co], flipped w[co][ci]): roles of the channel strides swap
   if (!replicate_pad) {
     HP_PROF("dconv3_dgrad", st);
-    return run_dconv(gy, w, nullptr, nullptr, gx, nullptr, 1.0f, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st);
+    return run_dconv(gy, w, nullptr, nullptr, gx, nullptr, 1.0f, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st, precision);
   }
   if (cin == 1 && cout == 1 && !use_mfma_c1()) {
     // single-channel layers (FeatureExtraction): the replicate fold inside the stencil kernel, one pass over (D, H, W)
@@ -1205,7 +1532,8 @@ extern "C" int hp_dconv3_backward_data(const float* gy, const float* w, float* g
   float* dpad = (float*)workspace;
   {
     HP_PROF("dconv3_dgrad", st);
-    int rc = run_dconv(gy, w, nullptr, nullptr, dpad, nullptr, 1.0f, B, cout, cin, D, H, W, D + 2, H + 2, W + 2, 2, 27, (long)cin * 27, 1, 0, st);
+    int rc = run_dconv(gy, w, nullptr, nullptr, dpad, nullptr, 1.0f, B, cout, cin, D, H, W, D + 2, H + 2, W + 2, 2, 27, (long)cin * 27, 1, 0, st,
+                       precision);
     if (rc) return rc;
   }
   HP_REQUIRE((long)B * cin * D < 65536 && H < 65536, "hp_dconv3_backward_data: volume too large for the fold grid");

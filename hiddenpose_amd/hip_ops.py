@@ -33,7 +33,31 @@ def _stream(t):
     return _lib.current_stream_handle(t.device)
 
 
-def _dconv3_grads(x, w, g, replicate, has_bias, need_dx):
+_DCONV_PRECISION = 0  # HP_PRECISION_FP32; 1 = HP_PRECISION_BF16 (forward and data gradient on v_mfma_f32_4x4x4_16b_bf16)
+
+
+def set_dconv_precision(name: str) -> str:
+    """Arithmetic of the thin-channel 3^3 convolutions (U-Net / FeatureExtraction layers with more than one channel):
+    "fp32" (exact, default) or "bf16" (operands rounded to bf16, fp32 accumulation: BASELINE configs[2], "bf16 with fp32
+    LCT").  Returns the previous setting; a node's backward uses the precision its forward ran with."""
+    global _DCONV_PRECISION
+    prev = _DCONV_NAMES[_DCONV_PRECISION]
+    _DCONV_PRECISION = _DCONV_NAMES.index(name)
+    return prev
+
+
+# "bf16emu" is a checker, not a mode to run: the EXACT kernels on operands rounded to bf16 beforehand (three extra passes per
+# convolution).  Products and accumulation type are those of the bf16 kernels, so the two agree up to fp32 summation order
+# through a whole network (tests/test_stages_gpu.py) -- which pins the bf16 path in situ, independent of how strongly a
+# randomly filled network amplifies the operand rounding itself.
+_DCONV_NAMES = ("fp32", "bf16", "bf16emu")
+
+
+def _emu(t, prec, cin, cout):
+    return t.bfloat16().float() if prec == 2 and not (cin == 1 and cout == 1) else t
+
+
+def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0):
     """(dx, dw, db) of y = conv3(x, w) + b given g = dL/dy; planar tensors."""
     L = _lib.lib()
     b, cin, d, h, wd = x.shape
@@ -45,8 +69,9 @@ def _dconv3_grads(x, w, g, replicate, has_bias, need_dx):
         gx = torch.empty_like(x)
         nb = int(L.hp_dconv3_backward_data_workspace_bytes(b, cin, d, h, wd, rp))
         ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
-        _lib.check(L.hp_dconv3_backward_data(g.data_ptr(), w.data_ptr(), gx.data_ptr(), b, cin, cout, d, h, wd, rp,
-                                             _lib.ptr(ws), st), "hp_dconv3_backward_data")
+        ge, we = _emu(g, prec, cin, cout), _emu(w, prec, cin, cout)
+        _lib.check(L.hp_dconv3_backward_data_p(ge.data_ptr(), we.data_ptr(), gx.data_ptr(), b, cin, cout, d, h, wd, rp, prec & 1,
+                                               _lib.ptr(ws), st), "hp_dconv3_backward_data_p")
     dw = torch.empty_like(w)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
     nbw = int(L.hp_dconv3_backward_weight_workspace_bytes(b, cin, cout, d, h, wd))
@@ -71,14 +96,16 @@ class _DConv3(torch.autograd.Function):
         cout = w.shape[0]
         y = torch.empty(b, cout, d, h, wd, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.hp_dconv3_forward_fused(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), _lib.ptr(res), y.data_ptr(), None,
-                                                 b, cin, cout, d, h, wd, 1 if replicate else 0, float(slope), _stream(x)),
-                       "hp_dconv3_forward_fused")
+            xe, we = _emu(x, _DCONV_PRECISION, cin, cout), _emu(w, _DCONV_PRECISION, cin, cout)
+            _lib.check(L.hp_dconv3_forward_fused_p(xe.data_ptr(), we.data_ptr(), _lib.ptr(bias), _lib.ptr(res), y.data_ptr(), None,
+                                                   b, cin, cout, d, h, wd, 1 if replicate else 0, float(slope),
+                                                   _DCONV_PRECISION & 1, _stream(x)), "hp_dconv3_forward_fused_p")
         if slope != 1.0:
             ctx.save_for_backward(x, w, y)
         else:
             ctx.save_for_backward(x, w)
         ctx.cfg = (replicate, bias is not None, res is not None, float(slope))
+        ctx.prec = _DCONV_PRECISION
         return y
 
     @staticmethod
@@ -95,7 +122,7 @@ class _DConv3(torch.autograd.Function):
             x, w = ctx.saved_tensors
             g = gy
         with torch.cuda.device(x.device):
-            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0])
+            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0], ctx.prec)
         return gx, dw, db, None, (g if has_res else None), None
 
 
@@ -122,14 +149,16 @@ class _ConvGnRelu(torch.autograd.Function):
         ws = torch.empty(int(L.hp_groupnorm_workspace_bytes(b, cout)) // 4 + 2, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _stream(x)
-            _lib.check(L.hp_dconv3_forward_fused(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), None, z.data_ptr(), stats.data_ptr(),
-                                                 b, cin, cout, d, h, wd, 0, 1.0, st), "hp_dconv3_forward_fused")
+            xe, we = _emu(x, _DCONV_PRECISION, cin, cout), _emu(w, _DCONV_PRECISION, cin, cout)
+            _lib.check(L.hp_dconv3_forward_fused_p(xe.data_ptr(), we.data_ptr(), _lib.ptr(bias), None, z.data_ptr(), stats.data_ptr(),
+                                                   b, cin, cout, d, h, wd, 0, 1.0, _DCONV_PRECISION & 1, st), "hp_dconv3_forward_fused_p")
             _lib.check(L.hp_groupnorm_relu_forward_v2(z.data_ptr(), y.data_ptr(), b, cout, groups, V, gamma.data_ptr(),
                                                       beta.data_ptr(), eps, stats.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                       aff[0].data_ptr(), aff[1].data_ptr(), ws.data_ptr(), st),
                        "hp_groupnorm_relu_forward_v2")
         ctx.save_for_backward(x, w, z, gamma, mean, rstd, aff)
         ctx.cfg = (groups, bias is not None)
+        ctx.prec = _DCONV_PRECISION
         return y
 
     @staticmethod
@@ -149,7 +178,7 @@ class _ConvGnRelu(torch.autograd.Function):
                                                        gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), aff[0].data_ptr(),
                                                        aff[1].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                                                        _stream(z)), "hp_groupnorm_relu_backward_v2")
-            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0])
+            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0], ctx.prec)
         return gx, dw, db, dgamma, dbeta, None, None
 
 

@@ -253,6 +253,16 @@ int hp_dconv3_forward_fused(const float* x, const float* w, const float* bias, c
 size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad);
 int hp_dconv3_backward_data(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H, int W,
                             int replicate_pad, void* workspace, void* stream);
+/* The same two calls with an arithmetic choice (BASELINE configs[2], "bf16 with fp32 LCT": the U-Net's convolutions on
+ * the bf16 matrix cores).  precision = HP_PRECISION_FP32: identical to the calls above.  HP_PRECISION_BF16: x (or gy) and
+ * w are rounded to bf16 (nearest even) on their way into LDS, products are exact, accumulation is fp32
+ * (v_mfma_f32_4x4x4_16b_bf16: four input channels per instruction); tensors stay fp32 in memory.  Single-channel
+ * (1 -> 1) layers always run exact. */
+int hp_dconv3_forward_fused_p(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                              double* stats, int B, int cin, int cout, int D, int H, int W, int replicate_pad, float slope,
+                              int precision, void* stream);
+int hp_dconv3_backward_data_p(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H, int W,
+                              int replicate_pad, int precision, void* workspace, void* stream);
 /* dw (Cout,Cin,3,3,3) and dbias (Cout, may be NULL) are overwritten.  workspace (device, sized by the query)
  * holds per-workgroup partial sums that a second kernel adds in a fixed order: no atomics, run-to-run
  * bit-identical. */

@@ -40,6 +40,81 @@ def test_dconv3(cin, cout, rep, dims):
     assert rel_l2(bg.grad, bd.grad) < 1e-5
 
 
+BF16_CASES = [c for c in CASES if not (c[0] == 1 and c[1] == 1)] + [(8, 8, False, (1, 9, 8, 70)), (12, 4, True, (1, 5, 9, 16)),
+                                                                  (20, 8, False, (2, 6, 4, 8)), (4, 4, True, (1, 6, 9, 68))]
+
+
+@pytest.mark.parametrize("cin,cout,rep,dims", BF16_CASES)
+def test_dconv3_bf16_operands(cin, cout, rep, dims):
+    """HP_PRECISION_BF16 (hip_ops.set_dconv_precision("bf16"), v_mfma_f32_4x4x4_16b_bf16): with x, w and the incoming
+    gradient ON the bf16 grid every product is exact, so forward and data gradient equal the float64 reference up to fp32
+    accumulation order -- the bars of the exact kernel; with arbitrary fp32 operands the error is the operand rounding
+    (2^-9 relative per operand).  The weight gradient stays on the exact kernel."""
+    g = torch.Generator().manual_seed(cin * 100 + cout + 1)
+    B, D, H, W = dims
+    grid = lambda t: t.bfloat16().float()
+    x = grid(torch.randn(B, cin, D, H, W, generator=g))
+    w = grid(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2)
+    b = torch.randn(cout, generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv3d(F.pad(xd, (1,) * 6, mode="replicate"), wd, bd) if rep else F.conv3d(xd, wd, bd, padding=1)
+    gy = grid(torch.randn(ref.shape, generator=g))
+    (ref * gy.double()).sum().backward()
+    prev = ops.set_dconv_precision("bf16")
+    try:
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+        y = ops._DConv3.apply(xg, wg, bg, rep)
+        (y * gy.cuda()).sum().backward()
+        assert rel_l2(y, ref) < 2e-6
+        assert rel_l2(xg.grad, xd.grad) < 2e-6
+        assert rel_l2(wg.grad, wd.grad) < 1e-5
+        assert rel_l2(bg.grad, bd.grad) < 1e-5
+        # arbitrary fp32 operands: bounded by the operand rounding
+        x2 = torch.randn(B, cin, D, H, W, generator=g)
+        w2 = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2
+        ref2 = F.conv3d(F.pad(x2.double(), (1,) * 6, mode="replicate"), w2.double(), b.double()) if rep else \
+            F.conv3d(x2.double(), w2.double(), b.double(), padding=1)
+        y2 = ops._DConv3.apply(x2.cuda(), w2.cuda(), b.cuda(), rep)
+        assert 1e-5 < rel_l2(y2, ref2) < 6e-3
+        # ... and equals the exact kernel on operands rounded beforehand (the "bf16emu" checker of test_stages_gpu.py)
+        ops.set_dconv_precision("bf16emu")
+        y2e = ops._DConv3.apply(x2.cuda(), w2.cuda(), b.cuda(), rep)
+        assert rel_l2(y2, y2e) < 2e-6
+    finally:
+        ops.set_dconv_precision(prev)
+    # and the switch is really off again: exact result on off-grid operands
+    y3 = ops._DConv3.apply(x2.cuda(), w2.cuda(), b.cuda(), rep)
+    assert rel_l2(y3, ref2) < 2e-6
+
+
+def test_conv_groupnorm_relu_bf16_operands():
+    """The DoubleConv half in bf16 arithmetic: statistics come from the bf16 kernel's epilogue, the backward's data gradient
+    runs on the same matrix-core path."""
+    g = torch.Generator().manual_seed(5)
+    grid = lambda t: t.bfloat16().float()
+    cin, cout, (B, D, H, W) = 8, 4, (2, 7, 8, 66)
+    x = grid(torch.randn(B, cin, D, H, W, generator=g))
+    w = grid(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.2)
+    b = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    xd, wd, bd, gd, btd = (t.double().requires_grad_(True) for t in (x, w, b, gamma, beta))
+    ref = F.relu(F.group_norm(F.conv3d(xd, wd, bd, padding=1), 4, gd, btd, 1e-5))
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy.double()).sum().backward()
+    prev = ops.set_dconv_precision("bf16")
+    try:
+        xg, wg, bg, gg, btg = (t.cuda().requires_grad_(True) for t in (x, w, b, gamma, beta))
+        y = ops.conv3_gn_relu(xg, wg, bg, gg, btg, 4, 1e-5)
+        (y * gy.cuda()).sum().backward()
+    finally:
+        ops.set_dconv_precision(prev)
+    assert rel_l2(y, ref) < 3e-6
+    # dz (the GroupNorm backward's output) is not on the bf16 grid: the data gradient carries its rounding
+    assert rel_l2(xg.grad, xd.grad) < 6e-3
+    assert rel_l2(wg.grad, wd.grad) < 2e-5
+    assert rel_l2(gg.grad, gd.grad) < 2e-5 and rel_l2(btg.grad, btd.grad) < 2e-5
+
+
 @pytest.mark.parametrize("cin,cout,rep,dims", [(1, 1, True, (2, 9, 10, 37)), (1, 1, False, (1, 12, 16, 64)), (4, 4, True, (1, 6, 9, 68))])
 def test_dconv3_fused_residual_leaky(cin, cout, rep, dims):
     """y = leaky(conv(x) + b + res, 0.2): ResConv3D's second half (feature_extraction.py:228-256) in one kernel."""

@@ -328,10 +328,10 @@ def test_train_step_batch4_vs_oracle():
 
 def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
     """BASELINE.json configs[2] in full (MODEL.CONV_PRECISION='bf16s': bf16 matrix cores AND bf16 activation storage in
-    the regressor; LCT, U-Net, norms, soft-argmax, losses, statistics, weights fp32): eval forward against the fp32
-    reference goldens at BF16_TOL, and one 128^3 train step against the 'bf16' mode (same arithmetic, fp32 storage) --
-    losses and gradient directions (this randomly filled network in train mode amplifies any rounding, see
-    test_bf16_train_step_against_fp32_mode_128: the bars are those of the bf16 mode itself)."""
+    the regressor, bf16 operands in the U-Net's multi-channel convolutions (MODEL.DCONV_PRECISION 'auto' -> 'bf16'); LCT,
+    norms, soft-argmax, losses, statistics, weights, U-Net tensors fp32): eval forward against the fp32
+    reference goldens at BF16_TOL, and one 128^3 train step (smooth filler) against the fp32 mode -- losses, heat-maps and
+    the direction of ten named gradients -- and against the same mode with an fp32 U-Net (MODEL.DCONV_PRECISION='fp32')."""
     BF16_TOL = 3e-2
     for T, N, name in ((32, 32, "e2e_T32_N32.npz"), (128, 128, "e2e_T128_N128.npz")):
         g = golden(name)
@@ -353,17 +353,25 @@ def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
             e_r = rel_l2(refine[:, :, ::8, ::8, ::8], g["eval_refine_sub"])
         with capsys.disabled():
             print(f"\n[bf16s] T={T}: heat rel-L2 {e_h:.3e}, refine rel-L2 {e_r:.3e}, MPJPE {e_j:.3e} voxels")
-        assert e_r < TOL and e_h < BF16_TOL and e_j < BF16_TOL * (N // 2)
+        # the refined volume passes 18 bf16-operand convolutions with GroupNorm in between; on the sparse, mostly-background
+        # LCT feature this randomly filled U-Net turns the 2.5e-3 per node into 4.2e-2 (T = 32) / 1.3e-1 (128^3) -- the
+        # kernels themselves are pinned per node in test_stages_gpu.py::test_unet_bf16_kernels_equal_exact_kernels_on_rounded_operands
+        assert e_r < 0.25 and e_h < BF16_TOL and e_j < BF16_TOL * (N // 2)
         del model
     B, T, N = 2, 128, 128
     meas = hpt.synthetic_meas(B, T, N).cuda()
     vol = hpt.synthetic_vol(B, T, N).cuda()
     joints = hpt.synthetic_joints(B, T // 2).cuda()
     out = {}
-    for mode in ("fp32", "bf16s"):
-        cfg = make_cfg(T, N, conv_precision=mode)
+    for mode in ("fp32", "bf16s", "bf16s+fp32unet"):
+        cfg = make_cfg(T, N, conv_precision=mode.split("+")[0])
+        if mode.endswith("fp32unet"):
+            cfg.MODEL.DCONV_PRECISION = "fp32"
         model = NlosPose(cfg)
-        hpt.fill_module(model)
+        assert model.dconv_precision == ("bf16" if mode == "bf16s" else "fp32")
+        # the SMOOTH filler (ReLU decisions far from rounding noise): with the default one this train-mode network amplifies
+        # a 1e-2 perturbation of the regressor's input (the bf16 U-Net) until gradients decorrelate, which says nothing
+        hpt.fill_module(model, smooth=True)
         model = model.cuda().train()
         criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
         loss, jl, vl, heat, refine = compute_loss(model, criterion, voxel_criterion, meas, vol, joints)
@@ -373,6 +381,7 @@ def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
         del model, optimizer, loss, heat, refine
         torch.cuda.empty_cache()
     (jl0, vl0, h0, g0), (jl1, vl1, h1, g1) = out["fp32"], out["bf16s"]
+    assert abs(out["bf16s+fp32unet"][1] / vl0 - 1) < 1e-6   # with an fp32 U-Net that branch does not touch a bf16 value
     cos = {}
     for k in ["feature_extraction.weights", "autoencoder.conv.double_conv.0.weight", "pose_net.conv1.weight",
               "pose_net.layer1.0.conv2.weight", "pose_net.layer2.0.conv2.weight", "pose_net.layer3.2.conv1.weight",
@@ -384,8 +393,9 @@ def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
     with capsys.disabled():
         print("[bf16s] 128^3 train vs fp32 mode: joint loss ratio %.3e, heat rel-L2 %.3e, min grad cosine %.4f" % (
             jl1 / jl0 - 1, rel_l2(h1, h0), min(cos.values())))
-    assert abs(vl1 / vl0 - 1) < 1e-6                 # the U-Net branch does not touch a bf16 tensor
-    assert abs(jl1 / jl0 - 1) < 0.25 and rel_l2(h1, h0) < 0.25 and min(cos.values()) > 0.4   # the bf16 mode's own bars
+    assert abs(vl1 / vl0 - 1) < 2e-2                 # the U-Net branch: bf16 operand rounding only
+    # measured with the smooth filler: joint loss -1.4e-4, heat-maps 3.0e-3, smallest gradient cosine 0.994
+    assert abs(jl1 / jl0 - 1) < 5e-3 and rel_l2(h1, h0) < 2e-2 and min(cos.values()) > 0.98
     from hiddenpose_amd import hip_ops as ops
     assert ops.get_conv_precision() == "fp32" and not ops._act_bf16
 

@@ -165,3 +165,65 @@ def test_feature_extraction_and_unet_vs_golden(golden):
     for k in ["conv.double_conv.0.weight", "conv.double_conv.1.weight", "enc4.encoder.1.double_conv.3.weight",
               "dec1.conv.double_conv.0.weight", "dec4.conv.double_conv.4.bias", "out.conv.weight", "out.conv.bias"]:
         assert rel_l2(named[k].grad, g["unet_g_" + k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("dims", [(2, 32, 32), (1, 128, 128)])
+def test_unet_bf16_kernels_equal_exact_kernels_on_rounded_operands(dims, capsys):
+    """HP_PRECISION_BF16 in situ: every conv -> GroupNorm -> ReLU node of a U-Net (all 18 layer shapes of the network, forward
+    + backward) with the bf16 matrix-core kernels (v_mfma_f32_4x4x4_16b_bf16) against the EXACT kernels fed operands rounded
+    to bf16 beforehand (hip_ops "bf16emu"): same products, same fp32 accumulation, only the summation order differs.  The
+    comparison is per node on IDENTICAL inputs (those of the fp32 chain): two bf16 chains cannot be compared end to end,
+    because operand rounding is a step function -- a 1e-7 difference in a node's output flips the rounding of ~3e-5 of the
+    next node's operands by a full bf16 ulp, and the difference grows as sqrt(delta * ulp) per node until it sits at the ulp
+    level (measured: 6e-8 -> 1.7e-5 -> 8e-5 -> ... -> 6e-3 over the 18 nodes).  For the same reason (and because the ReLU
+    mask of the backward is a step function of z) the data gradient is checked on the node's convolution alone, for one
+    given output gradient."""
+    from hiddenpose_amd.unet3d import UNet3d
+
+    B, T, N = dims
+    un = UNet3d(in_channels=1, n_channels=4)
+    hpt.fill_module(un, "autoencoder.")
+    un = un.cuda()
+    u0 = (hpt.synthetic_meas(B, T, N, "uniform", seed=103) * 10.0).cuda()
+    nodes = []
+    orig = ops.conv3_gn_relu
+
+    def record(x, w, b, gw, gb, groups, eps):
+        nodes.append((x.detach(), w.detach(), b.detach(), gw.detach(), gb.detach(), groups, eps))
+        return orig(x, w, b, gw, gb, groups, eps)
+
+    ops.conv3_gn_relu = record
+    try:
+        with torch.no_grad():
+            y_fp32 = un(u0)
+            ops.conv3_gn_relu = orig
+            prev = ops.set_dconv_precision("bf16")
+            try:
+                y_bf16 = un(u0)
+            finally:
+                ops.set_dconv_precision(prev)
+    finally:
+        ops.conv3_gn_relu = orig
+    assert len(nodes) == 18
+    worst = [0.0, 0.0]
+    gen = torch.Generator().manual_seed(3)
+    for x, w, b, gw, gb, groups, eps in nodes:
+        gy = torch.randn(x.shape[0], w.shape[0], *x.shape[2:], generator=gen).cuda()
+        out = {}
+        for mode in ("bf16", "bf16emu"):
+            prev = ops.set_dconv_precision(mode)
+            try:
+                with torch.no_grad():
+                    y = orig(x, w, b, gw, gb, groups, eps)          # convolution + statistics epilogue + GroupNorm + ReLU
+                xl = x.clone().requires_grad_(True)
+                (ops._DConv3.apply(xl, w, b, False) * gy).sum().backward()   # the convolution's data gradient for ONE given gy
+            finally:
+                ops.set_dconv_precision(prev)
+            out[mode] = (y, xl.grad)
+        errs = (rel_l2(out["bf16"][0], out["bf16emu"][0]), rel_l2(out["bf16"][1], out["bf16emu"][1]))
+        worst = [max(p, q) for p, q in zip(worst, errs)]
+        assert errs[0] < 1e-6 and errs[1] < 2e-6, (tuple(x.shape), w.shape[0], errs)
+    with capsys.disabled():
+        print(f"\n[unet bf16] {dims}: 18 nodes, kernel vs rounded-operand emulation: y {worst[0]:.1e}, dx {worst[1]:.1e};  "
+              f"whole U-Net, bf16 vs fp32 arithmetic: y {rel_l2(y_bf16, y_fp32):.2e}")
+    assert 1e-4 < rel_l2(y_bf16, y_fp32) < 6e-2   # the mode really rounds; ~2.5e-3 per node, no blow-up

@@ -1,0 +1,9 @@
+set -x
+mkdir -p gpurun_out/r3
+export PYTHONUNBUFFERED=1
+for s in 2 3 4; do
+HP_DCONV_SETS=$s timeout -k 10 200 python tools/time_dconv_layers.py > gpurun_out/r3/dconv_layers_fp32_s$s.log 2>&1
+HP_DCONV_SETS=$s HP_TIME_DCONV_PRECISION=bf16 timeout -k 10 200 python tools/time_dconv_layers.py > gpurun_out/r3/dconv_layers_bf16_s$s.log 2>&1
+done
+cd gpurun_out/r3
+paste -d'\n' dconv_layers_fp32_s2.log dconv_layers_fp32_s3.log dconv_layers_fp32_s4.log dconv_layers_bf16_s2.log dconv_layers_bf16_s3.log dconv_layers_bf16_s4.log | grep -v "amdgpu.ids\|calibration" | cut -c1-130

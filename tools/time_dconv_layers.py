@@ -1,9 +1,12 @@
 """Per-layer timing of the thin-channel 3^3 convolutions at the U-Net / FeatureExtraction shapes of a T x N x N volume:
-    python tools/time_dconv_layers.py [T N]      (default 1024 256)"""
+    python tools/time_dconv_layers.py [T N]      (default 1024 256; HP_TIME_DCONV_PRECISION=bf16: forward / data gradient
+    on the bf16 matrix cores)"""
 import sys; sys.path.insert(0, '.')
+import os
 import torch
 from hiddenpose_amd import _lib
 T, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 256)
+PREC = 1 if os.environ.get('HP_TIME_DCONV_PRECISION', 'fp32') == 'bf16' else 0
 L = _lib.lib(); st = torch.cuda.current_stream().cuda_stream
 layers = [("FE 1->1 replicate", 1, 1, 1, 1), ("FE 1->1 zero (box)", 1, 1, 1, 0), ("conv 1->4", 1, 4, 1, 0), ("conv/dec4 4->4", 4, 4, 1, 0),
           ("dec4 8->4", 8, 4, 1, 0), ("enc1 4->8", 4, 8, 2, 0), ("enc1 8->8", 8, 8, 2, 0), ("dec3 16->4", 16, 4, 2, 0),
@@ -26,8 +29,8 @@ for name, cin, cout, ds, rep in layers:
     y = torch.empty_like(g); gx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(cout, device='cuda')
     ws = torch.empty(int(L.hp_dconv3_backward_data_workspace_bytes(1, cin, D, H, W, rep)) // 4 + 1, device='cuda')
     wsw = torch.empty(int(L.hp_dconv3_backward_weight_workspace_bytes(1, cin, cout, D, H, W)) // 4, device='cuda')
-    f = timeit(lambda: L.hp_dconv3_forward(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 1, cin, cout, D, H, W, rep, st))
-    d = timeit(lambda: L.hp_dconv3_backward_data(g.data_ptr(), w.data_ptr(), gx.data_ptr(), 1, cin, cout, D, H, W, rep, ws.data_ptr(), st))
+    f = timeit(lambda: L.hp_dconv3_forward_fused_p(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, 1, cin, cout, D, H, W, rep, 1.0, PREC, st))
+    d = timeit(lambda: L.hp_dconv3_backward_data_p(g.data_ptr(), w.data_ptr(), gx.data_ptr(), 1, cin, cout, D, H, W, rep, PREC, ws.data_ptr(), st))
     wg = timeit(lambda: L.hp_dconv3_backward_weight(x.data_ptr(), g.data_ptr(), dw.data_ptr(), db.data_ptr(), 1, cin, cout, D, H, W, rep, wsw.data_ptr(), st))
     V = D * H * W
     gf = 2 * 27 * cin * cout * V / 1e9
