@@ -69,6 +69,7 @@ SIGNATURES = {
     "hp_dconv3_backward_data": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_dconv3_forward_fused_p": (_i, [_fp, _fp, _fp, _fp, _fp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "hp_dconv3_backward_data_p": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "hp_dconv3_backward_weight_p": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_dconv3_backward_weight_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "hp_dconv3_backward_weight": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hp_groupnorm_workspace_bytes": (_sz, [_i, _i]),

@@ -53,14 +53,7 @@ __global__ __launch_bounds__(256) void k_fold_replicate(const float* __restrict_
 constexpr int WG_TY = 8, WG_TX = 64, WG_PX = 68, WG_PY = WG_TY + 2, WG_PLANE = 4 * WG_PY * WG_PX;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// FOLD (with PADMODE 0, pad 1, flip 1): the data gradient of a REPLICATE-padded convolution in one pass.  The adjoint of
-// "clamp the read position" folds the weight of every tap that pointed outside the volume onto the border voxel's own
-// position, independently per axis: at coordinate 0 the centre weight of that axis gains the weight of index 2 (flipped
-// order), at the last coordinate that of index 0 -- the zero-padded correlation with position-dependent weights on the six
-// faces.  y rows are fixed per thread (weights folded once), z planes per step (centre-plane weights summed in a uniform
-// branch), x ends are two corrections per plane for the lanes that own x = 0 / x = W - 1.  Replaces the correlation on the
-// (D+2)(H+2)(W+2) halo domain + k_fold_replicate (a second pass over a larger volume).
-template <int PADMODE, bool FOLD = false>
+template <int PADMODE>
 __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ g,
                                                            int cin, int cout,
                                                            int D, int H, int W, int tiles_x, int tiles_y, int zchunk,
@@ -230,6 +223,211 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   }
   __syncthreads();
   // partial[pair][workgroup of the pair][448]: plain stores, summed by k_dconv3_wgrad_reduce in a fixed order
+  const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long)gridDim.x * gridDim.y;
+  float* out = partial + ((long)blockIdx.z * nwg + wg) * (16 * 28);
+  for (int u = tid; u < 16 * 28; u += 256) out[u] = part[0][u] + part[1][u] + part[2][u] + part[3][u];
+}
+
+
+// bf16-operand weight gradient (HP_PRECISION_BF16): v_mfma_f32_4x4x4_16b_bf16 with K = FOUR CONSECUTIVE VOXELS of an x-run,
+//     D_b[i][j] += sum_{k<4} g[co0+i][v_{4b+k}] * x[ci0+j][v_{4b+k} + tap]
+// so one instruction covers a whole 64-voxel row (16 blocks x 4) where the exact kernel needs four.  Lane 4b+i supplies four
+// consecutive g values (one 16-byte global load, rounded to bf16), lane 4b+j the four x values starting at voxel 4b + dx of
+// the shifted row: the ring keeps the planes PLANAR in bf16 (one row = 68 halves), a lane reads the eight halves 4b .. 4b+7
+// of its row once per (dz, dy) -- two 8-byte-aligned ds_read_b64 -- and cuts the three dx windows out of them in registers
+// (dx = 1: two v_alignbit; dx = 2: the middle four halves, no instruction): 3 MFMAs per 2 LDS reads instead of 12 per 12.
+// The bias gradient is summed exactly (fp32, from the unrounded g).  Needs W % 4 == 0 and a 16-byte aligned g (the caller
+// falls back to the exact kernel otherwise).  Same tiling, z walk, partial layout and reduction kernel as above.
+using wbf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using wbf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using ws16x4 = __attribute__((ext_vector_type(4))) short;
+using wf32x2 = __attribute__((ext_vector_type(2))) float;
+using wu32x2 = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ wu32x2 wpack_bf16x4(float a, float b, float c, float d) {
+  const wbf16x2 lo = __builtin_convertvector((wf32x2){a, b}, wbf16x2);
+  const wbf16x2 hi = __builtin_convertvector((wf32x2){c, d}, wbf16x2);
+  return (wu32x2){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+constexpr int WH_ROW = WG_PX;                       // halves per row (68: 136 bytes, rows stay 8-byte aligned)
+constexpr int WH_PLANE = 4 * WG_PY * WH_ROW;        // halves per ring slot (4 channels x 10 rows)
+constexpr int WH_GROUPS = WH_ROW / 4;               // 17 four-cell groups per row
+constexpr int WH_ITEMS = 4 * WG_PY * WH_GROUPS;     // 680 staging items (channel, row, group) per plane
+
+template <int PADMODE>
+__global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __restrict__ x, const float* __restrict__ g,
+                                                              int cin, int cout, int D, int H, int W, int tiles_x, int tiles_y,
+                                                              int zchunk, int cig_n, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) unsigned short ring[4 * WH_PLANE];
+  __shared__ float part[4][28 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = lane >> 2, sub = lane & 3;
+  int t_ = blockIdx.x;
+  const int bx = t_ % tiles_x;
+  t_ /= tiles_x;
+  const int by = t_ % tiles_y;
+  const int bz = t_ / tiles_y;
+  const int b = blockIdx.y;
+  const int cig = blockIdx.z % cig_n, cog = blockIdx.z / cig_n;
+  const int x0 = bx * WG_TX, y0 = by * WG_TY;
+  const int zb = bz * zchunk, ze = min(D, zb + zchunk);
+  const int co = cog * 4 + sub;
+  const bool co_ok = co < cout;
+  const long cs = (long)D * H * W;
+  const float* xb = x + ((long)b * cin + cig * 4) * cs;
+  const bool want_db = cig == 0;
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+  // staging item it = tid + 256 k: (channel c, row ly, group gq) -> cells lx = 4 gq .. 4 gq + 3 of that row, packed into one
+  // 8-byte LDS write; every cell has its own fixed offset (out of range = zero padding / past the volume / past cin)
+  constexpr int SKI = (WH_ITEMS + 255) / 256;
+  unsigned soff[SKI][4];
+#pragma unroll
+  for (int k = 0; k < SKI; ++k) {
+    const int it = tid + 256 * k;
+    const int c = it / (WG_PY * WH_GROUPS);
+    const int r = it - c * (WG_PY * WH_GROUPS);
+    const int ly = r / WH_GROUPS, gq = r - ly * WH_GROUPS;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int lx = 4 * gq + m;
+      int yy = y0 + ly - 1, xx = x0 + lx - 1;
+      bool ok = it < WH_ITEMS && lx < 66 && cig * 4 + c < cin;
+      if (PADMODE == 1) {
+        yy = min(max(yy, 0), H - 1);
+        xx = min(max(xx, 0), W - 1);
+      } else {
+        ok = ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      }
+      soff[k][m] = ok ? (unsigned)(((long)c * cs + (long)yy * W + xx) * 4) : OOB;
+    }
+  }
+  auto stage_load = [&](int zp, float (&v)[SKI][4]) {
+    int zz = zp;
+    bool zok = (unsigned)zz < (unsigned)D;
+    if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
+    if (zok) {
+      const unsigned zs = (unsigned)((long)zz * H * W * 4);
+#pragma unroll
+      for (int k = 0; k < SKI; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[k][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k][m], zs, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < SKI; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[k][m] = 0.f;
+    }
+  };
+  auto stage_store = [&](int zp, const float (&v)[SKI][4]) {
+    wu32x2* dst = (wu32x2*)(ring + (zp & 3) * WH_PLANE) + tid;   // item it occupies halves 4 it .. 4 it + 3 of the slot
+#pragma unroll
+    for (int k = 0; k < SKI; ++k)
+      if (tid + 256 * k < WH_ITEMS) dst[256 * k] = wpack_bf16x4(v[k][0], v[k][1], v[k][2], v[k][3]);
+  };
+  auto stage = [&](int zp) {
+    float v[SKI][4];
+    stage_load(zp, v);
+    stage_store(zp, v);
+  };
+
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float sdb = 0.f;   // exact bias-gradient partial of output channel `sub` (this lane's four voxels per row)
+
+  if (zb < ze) {
+    stage(zb - 1);
+    stage(zb);
+    stage(zb + 1);
+  }
+  __syncthreads();
+  // this lane's window inside a slot for row r: halves (sub * PY + 2 * wave + r + dy) * ROW + 4 * blk .. + 7
+  const int lbase = (sub * WG_PY + 2 * wave) * WH_ROW + 4 * blk;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, OOB, 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int xv = x0 + 4 * blk;
+  const unsigned goff = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;   // W % 4 == 0: the four voxels are in or out together
+  auto g_load = [&](int z, float4 (&gv)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = y0 + 2 * wv + r;   // scalar
+      if (z < ze && y < H) {
+        gv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, goff, (unsigned)(((long)z * H + y) * W * 4), 0));
+      } else {
+        gv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto multiply = [&](int z, const float4 (&gv)[2]) {
+    const unsigned short* p0 = ring + ((z - 1) & 3) * WH_PLANE + lbase;
+    const unsigned short* p1 = ring + (z & 3) * WH_PLANE + lbase;
+    const unsigned short* p2 = ring + ((z + 1) & 3) * WH_PLANE + lbase;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const ws16x4 ga = __builtin_bit_cast(ws16x4, wpack_bf16x4(gv[r].x, gv[r].y, gv[r].z, gv[r].w));
+      if (want_db) sdb += (gv[r].x + gv[r].y) + (gv[r].z + gv[r].w);
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const unsigned short* pl = (dz == 0 ? p0 : dz == 1 ? p1 : p2) + r * WH_ROW;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const wu32x2 lo = *(const wu32x2*)(pl + dy * WH_ROW), hi = *(const wu32x2*)(pl + dy * WH_ROW + 4);
+          const wu32x2 w1 = {__builtin_amdgcn_alignbit(lo[1], lo[0], 16), __builtin_amdgcn_alignbit(hi[0], lo[1], 16)};
+          const wu32x2 w2 = {lo[1], hi[0]};
+          const int t = (dz * 3 + dy) * 3;
+          acc[t] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ga, __builtin_bit_cast(ws16x4, lo), acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ga, __builtin_bit_cast(ws16x4, w1), acc[t + 1], 0, 0, 0);
+          acc[t + 2] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ga, __builtin_bit_cast(ws16x4, w2), acc[t + 2], 0, 0, 0);
+        }
+      }
+    }
+  };
+  float nA[SKI][4], nB[SKI][4];
+  float4 gA[2], gB[2];
+  if (zb < ze) g_load(zb, gA);
+  if (zb + 1 < ze) stage_load(zb + 2, nA);
+  for (int z = zb; z < ze; z += 2) {
+    if (z + 2 < ze) stage_load(z + 3, nB);
+    g_load(z + 1, gB);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(z, gA);
+    if (z + 1 < ze) stage_store(z + 2, nA);
+    __syncthreads();
+    if (z + 1 < ze) {
+      if (z + 3 < ze) stage_load(z + 4, nA);
+      g_load(z + 2, gA);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(z + 1, gB);
+      if (z + 2 < ze) stage_store(z + 3, nB);
+      __syncthreads();
+    }
+  }
+  // sum the 16 blocks: lanes with equal (lane & 3) hold the same (., j) column of different voxels
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[t][i];
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      acc[t][i] = v;
+    }
+  sdb += __shfl_xor(sdb, 4);
+  sdb += __shfl_xor(sdb, 8);
+  sdb += __shfl_xor(sdb, 16);
+  sdb += __shfl_xor(sdb, 32);
+  if (blk == 0) {
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[wave][(i * 4 + sub) * 28 + t] = acc[t][i];  // [co i][ci j][tap]
+    // slot 27 = bias gradient of output channel i, read by the reduction from column j = 0: this lane owns channel `sub`
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) part[wave][(sub * 4 + jj) * 28 + 27] = jj == 0 ? sdb : 0.f;
+  }
+  __syncthreads();
   const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x, nwg = (long)gridDim.x * gridDim.y;
   float* out = partial + ((long)blockIdx.z * nwg + wg) * (16 * 28);
   for (int u = tid; u < 16 * 28; u += 256) out[u] = part[0][u] + part[1][u] + part[2][u] + part[3][u];
@@ -1571,15 +1769,34 @@ extern "C" size_t hp_dconv3_backward_weight_workspace_bytes(int B, int cin, int 
   return sizeof(float) * (size_t)q.cog_n * q.cig_n * q.nwg * 16 * 28;
 }
 
+extern "C" int hp_dconv3_backward_weight_p(const float* x, const float* gy, float* dw, float* dbias, int B, int cin,
+                                           int cout, int D, int H, int W, int replicate_pad, int precision, void* workspace,
+                                           void* stream);
+
 extern "C" int hp_dconv3_backward_weight(const float* x, const float* gy, float* dw, float* dbias, int B, int cin,
                                          int cout, int D, int H, int W, int replicate_pad, void* workspace, void* stream) {
+  return hp_dconv3_backward_weight_p(x, gy, dw, dbias, B, cin, cout, D, H, W, replicate_pad, HP_PRECISION_FP32, workspace, stream);
+}
+
+extern "C" int hp_dconv3_backward_weight_p(const float* x, const float* gy, float* dw, float* dbias, int B, int cin,
+                                           int cout, int D, int H, int W, int replicate_pad, int precision, void* workspace,
+                                           void* stream) {
   HP_REQUIRE(x && gy && dw && workspace && B > 0, "hp_dconv3_backward_weight: bad argument");
+  HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_dconv3_backward_weight_p: precision must be fp32 or bf16");
   hipStream_t st = (hipStream_t)stream;
   const WgradGeom q = wgrad_geom(B, cin, cout, D, H, W);
   dim3 grid((unsigned)(q.tiles_x * q.tiles_y * q.zsplit), (unsigned)B, (unsigned)(q.cog_n * q.cig_n));
   float* partial = (float*)workspace;
   HP_PROF("dconv3_wgrad", st);
-  if (cin == 1) {
+  // bf16 operands: multi-channel layers whose rows allow the 16-byte g loads; everything else stays on the exact kernels
+  if (precision == HP_PRECISION_BF16 && cin > 1 && W % 4 == 0 && ((uintptr_t)gy & 15) == 0) {
+    if (replicate_pad)
+      hipLaunchKernelGGL((k_dconv3_wgrad_bf16<1>), grid, dim3(256), 0, st, x, gy, cin, cout, D, H, W, q.tiles_x, q.tiles_y,
+                         q.zchunk, q.cig_n, partial);
+    else
+      hipLaunchKernelGGL((k_dconv3_wgrad_bf16<0>), grid, dim3(256), 0, st, x, gy, cin, cout, D, H, W, q.tiles_x, q.tiles_y,
+                         q.zchunk, q.cig_n, partial);
+  } else if (cin == 1) {
     if (replicate_pad)
       hipLaunchKernelGGL((k_dconv3_wgrad_mfma_c1<1>), grid, dim3(256), 0, st, x, gy, cout, D, H, W, q.tiles_x, q.tiles_y, q.zchunk,
                          partial);

@@ -8,6 +8,8 @@ HIP device.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -51,6 +53,8 @@ def set_dconv_precision(name: str) -> str:
 # through a whole network (tests/test_stages_gpu.py) -- which pins the bf16 path in situ, independent of how strongly a
 # randomly filled network amplifies the operand rounding itself.
 _DCONV_NAMES = ("fp32", "bf16", "bf16emu")
+# A/B switch: HP_DCONV_WGRAD_BF16=0 keeps the weight gradients of the bf16 mode on the exact kernel
+_DCONV_WGRAD_BF16 = os.environ.get("HP_DCONV_WGRAD_BF16", "1") != "0"
 
 
 def _emu(t, prec, cin, cout):
@@ -76,8 +80,11 @@ def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0):
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
     nbw = int(L.hp_dconv3_backward_weight_workspace_bytes(b, cin, cout, d, h, wd))
     wsw = torch.empty(nbw // 4, dtype=torch.float32, device=x.device)
-    _lib.check(L.hp_dconv3_backward_weight(x.data_ptr(), g.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
-                                           d, h, wd, rp, wsw.data_ptr(), st), "hp_dconv3_backward_weight")
+    wprec = prec if _DCONV_WGRAD_BF16 else 0
+    emu_w = wprec == 2 and cin > 1 and wd % 4 == 0   # the layers the bf16 weight-gradient kernel takes (others run exact)
+    xe, ge = (x.bfloat16().float(), g.bfloat16().float()) if emu_w else (x, g)
+    _lib.check(L.hp_dconv3_backward_weight_p(xe.data_ptr(), ge.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
+                                             d, h, wd, rp, wprec & 1, wsw.data_ptr(), st), "hp_dconv3_backward_weight_p")
     return gx, dw, db
 
 

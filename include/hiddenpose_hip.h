@@ -263,6 +263,11 @@ int hp_dconv3_forward_fused_p(const float* x, const float* w, const float* bias,
                               int precision, void* stream);
 int hp_dconv3_backward_data_p(const float* gy, const float* w, float* gx, int B, int cin, int cout, int D, int H, int W,
                               int replicate_pad, int precision, void* workspace, void* stream);
+/* weight gradient with the same arithmetic choice: HP_PRECISION_BF16 rounds x and gy to bf16 (K = four consecutive voxels
+ * per v_mfma_f32_4x4x4_16b_bf16), accumulates in fp32 and sums the bias gradient exactly; layers with cin == 1, W % 4 != 0
+ * or a gy not aligned to 16 bytes run exact.  Workspace as for hp_dconv3_backward_weight. */
+int hp_dconv3_backward_weight_p(const float* x, const float* gy, float* dw, float* dbias, int B, int cin, int cout, int D,
+                                int H, int W, int replicate_pad, int precision, void* workspace, void* stream);
 /* dw (Cout,Cin,3,3,3) and dbias (Cout, may be NULL) are overwritten.  workspace (device, sized by the query)
  * holds per-workgroup partial sums that a second kernel adds in a fixed order: no atomics, run-to-run
  * bit-identical. */

@@ -49,7 +49,8 @@ def test_dconv3_bf16_operands(cin, cout, rep, dims):
     """HP_PRECISION_BF16 (hip_ops.set_dconv_precision("bf16"), v_mfma_f32_4x4x4_16b_bf16): with x, w and the incoming
     gradient ON the bf16 grid every product is exact, so forward and data gradient equal the float64 reference up to fp32
     accumulation order -- the bars of the exact kernel; with arbitrary fp32 operands the error is the operand rounding
-    (2^-9 relative per operand).  The weight gradient stays on the exact kernel."""
+    (2^-9 relative per operand).  The weight gradient takes the bf16 kernel where W % 4 == 0 and cin > 1 (K = four consecutive
+    voxels per instruction; bias gradient summed exactly) and the exact kernel elsewhere."""
     g = torch.Generator().manual_seed(cin * 100 + cout + 1)
     B, D, H, W = dims
     grid = lambda t: t.bfloat16().float()
@@ -77,9 +78,16 @@ def test_dconv3_bf16_operands(cin, cout, rep, dims):
         y2 = ops._DConv3.apply(x2.cuda(), w2.cuda(), b.cuda(), rep)
         assert 1e-5 < rel_l2(y2, ref2) < 6e-3
         # ... and equals the exact kernel on operands rounded beforehand (the "bf16emu" checker of test_stages_gpu.py)
-        ops.set_dconv_precision("bf16emu")
-        y2e = ops._DConv3.apply(x2.cuda(), w2.cuda(), b.cuda(), rep)
-        assert rel_l2(y2, y2e) < 2e-6
+        gy2 = torch.randn(ref2.shape, generator=g).cuda()
+        grads = {}
+        for mode in ("bf16", "bf16emu"):
+            ops.set_dconv_precision(mode)
+            xl, wl = x2.cuda().requires_grad_(True), w2.cuda().requires_grad_(True)
+            yy = ops._DConv3.apply(xl, wl, b.cuda(), rep)
+            (yy * gy2).sum().backward()
+            grads[mode] = (yy.detach(), xl.grad, wl.grad)
+        for a, e, bar in zip(grads["bf16"], grads["bf16emu"], (2e-6, 2e-6, 1e-5)):
+            assert rel_l2(a, e) < bar
     finally:
         ops.set_dconv_precision(prev)
     # and the switch is really off again: exact result on off-grid operands

@@ -107,15 +107,17 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
 
 @pytest.mark.gpu
 def test_bf16_storage_mode_trains_like_fp32():
-    """BASELINE configs[2]'s per-GPU arithmetic (`bf16s`: bf16 matrix cores, bf16 activations / activation gradients in HBM,
-    fp32 LCT, statistics, weights and optimizer) against the fp32 mode as TRAINING, not as one step: twenty Adam steps on
-    one fixed 128^3 batch from the same initialisation (reference init, seed 410).  Measured: fp32 21058 -> 13250
-    (monotone), bf16s 19856 -> 14317 (falls to 14161 by step 5, then wanders within 14300 .. 14990): the randomly
+    """BASELINE configs[2]'s per-GPU arithmetic (`bf16s`: bf16 matrix cores, bf16 activations / activation gradients in HBM
+    in the regressor, bf16 operands in the U-Net's convolutions; fp32 LCT, statistics, weights and optimizer) against the
+    fp32 mode as TRAINING, not as one step: twenty Adam steps on one fixed 128^3 batch from the same initialisation
+    (reference init, seed 410).  fp32 falls 21058 -> 13330, monotone.  The bf16s curve is noisier -- the randomly
     initialised network amplifies the 2^-9 rounding of every activation (the two FORWARD losses already differ by 5.7 % at
-    step 1), so the bf16s curve is noisier -- and, the split-K weight gradients summing with atomics, not identical run to
-    run: single steps have been seen 20 % off the fp32 curve -- and ends ~8 % above it after 20 steps.  Bars: both fall by
-    > 20 %; the bf16s curve never strays more than 30 % from the fp32 one; its best loss of the last five steps is within
-    12 % of fp32's and its last loss within 15 %."""
+    step 1) -- and, the split-K weight gradients summing with atomics, not identical run to run.  Measured over six runs per
+    variant (tools/dbg/bf16s_curves.py, gpurun_out/r3/curves_*.log), final loss above fp32's: +0.8 .. +7.3 % with an fp32
+    U-Net (MODEL.DCONV_PRECISION = 'fp32'), +1.5 .. +20 % with the bf16 U-Net that `bf16s` selects (mean +11 %; the same with
+    its weight gradients kept exact: it is the forward / data-gradient rounding inside the GroupNorm'd U-Net); single steps
+    up to 29 % off the fp32 curve.  Bars (from that spread): both fall by > 20 %; the bf16s curve never strays more than
+    40 % from the fp32 one; its best loss of the last five steps is within 25 % of fp32's and its last loss within 30 %."""
     from hiddenpose_amd import testing as hpt
     from hiddenpose_amd.config import make_cfg
     from hiddenpose_amd.NlosPose import NlosPose
@@ -138,9 +140,9 @@ def test_bf16_storage_mode_trains_like_fp32():
     print("bf16s:", " ".join(f"{v:.4g}" for v in b))
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
     assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]
-    assert np.abs(b / a - 1).max() < 0.30, (a, b)
-    assert abs(b[-5:].min() / a[-5:].min() - 1) < 0.12
-    assert abs(b[-1] / a[-1] - 1) < 0.15
+    assert np.abs(b / a - 1).max() < 0.40, (a, b)
+    assert abs(b[-5:].min() / a[-5:].min() - 1) < 0.25
+    assert abs(b[-1] / a[-1] - 1) < 0.30
 
 
 @pytest.mark.gpu

@@ -31,7 +31,7 @@ for name, cin, cout, ds, rep in layers:
     wsw = torch.empty(int(L.hp_dconv3_backward_weight_workspace_bytes(1, cin, cout, D, H, W)) // 4, device='cuda')
     f = timeit(lambda: L.hp_dconv3_forward_fused_p(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, 1, cin, cout, D, H, W, rep, 1.0, PREC, st))
     d = timeit(lambda: L.hp_dconv3_backward_data_p(g.data_ptr(), w.data_ptr(), gx.data_ptr(), 1, cin, cout, D, H, W, rep, PREC, ws.data_ptr(), st))
-    wg = timeit(lambda: L.hp_dconv3_backward_weight(x.data_ptr(), g.data_ptr(), dw.data_ptr(), db.data_ptr(), 1, cin, cout, D, H, W, rep, wsw.data_ptr(), st))
+    wg = timeit(lambda: L.hp_dconv3_backward_weight_p(x.data_ptr(), g.data_ptr(), dw.data_ptr(), db.data_ptr(), 1, cin, cout, D, H, W, rep, PREC, wsw.data_ptr(), st))
     V = D * H * W
     gf = 2 * 27 * cin * cout * V / 1e9
     gb = 4 * V * (cin + cout) / 1e9
