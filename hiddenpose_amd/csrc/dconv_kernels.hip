@@ -684,8 +684,6 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
   const bool xin = x0 + lane < Wo;
   const unsigned xoff = xin ? (unsigned)((x0 + lane) * 4) : 0x80000000u;
   const long ybase = ((long)b * cout + cog * 4) * ocs;   // this workgroup's 4 output channels: offsets within them fit 31 bits
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
   float bv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bv[i] = bias && cog * 4 + i < cout ? bias[cog * 4 + i] : 0.f;
@@ -708,7 +706,6 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     // offset -- no vector address arithmetic per plane (while a wave streams fp32 MFMAs the other waves of its SIMD issue no
     // vector-ALU instruction: tools/micro/mfma_coexec.hip; each one here is paid in matrix-pipe time).
     constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
     unsigned soff[SK];
 #pragma unroll
     for (int k = 0; k < SK; ++k) {
@@ -728,14 +725,25 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     }
     // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
     // (stage_store) after it, so the global-memory latency hides behind the MFMAs
+    // Two forms of every per-step piece.  The STEADY-STATE form (suffix _fast) carries no per-step condition: its plane is
+    // known to lie inside the volume and its step inside the chunk, so the loop body is straight-line code around the
+    // loop-invariant branches.  The generic form (chunk ends, tiny volumes) branches and zero-fills.  Why two: with the
+    // conditions inside the main loop the compiler merged the rotating register sets with v_mov copies at the joins, and a
+    // copy (or a zero-fill) of a register whose load is still in flight needs s_waitcnt vmcnt(0) -- the prefetch was waited
+    // for at the top of every step, whatever the number of sets (seen in the ISA; round 3).
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+    auto stage_load_fast = [&](int zin, float (&v)[SK]) {   // plane known to lie inside the volume (or clamped into it)
+      const int zz = PADMODE == 1 ? min(max(zin, 0), Di - 1) : zin;
+      const unsigned zs = (unsigned)((long)zz * Hi * Wi * 4);
+#pragma unroll
+      for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+    };
     auto stage_load = [&](int zin, float (&v)[SK]) {
       int zz = zin;
       bool zok = (unsigned)zz < (unsigned)Di;
       if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
       if (zok) {  // workgroup-uniform
-        const unsigned zs = (unsigned)((long)zz * Hi * Wi * 4);
-#pragma unroll
-        for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+        stage_load_fast(zz, v);
       } else {
 #pragma unroll
         for (int k = 0; k < SK; ++k) v[k] = 0.f;
@@ -764,29 +772,60 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     // phase: one memory round trip hidden behind the MFMAs instead of eight exposed ones (a load per output row and channel,
     // each waited for on the spot), and the wait for it leaves the younger plane prefetches in flight.
     const bool last = c0 + 4 >= cin;
-    auto epi_load = [&](int z, EpiVals& ev) {
+    const bool need_a = c0 != 0, need_r = last && res != nullptr;   // sweep constants
+    // `ok` of an output row / channel of a step and its scalar offset
+    auto out_ok = [&](int z, bool valid, int r, int i) { return valid && y0 + 2 * wv + r < Ho && cog * 4 + i < cout; };
+    auto out_off = [&](int z, int r, int i) { return (unsigned)(((long)i * ocs + ((long)z * Ho + (y0 + 2 * wv + r)) * Wo) * 4); };
+    // steady-state form: no step / row conditions beyond the loop-invariant ones, and NO write to ev on the paths that do not
+    // load (a v_mov into a register some other path loads into costs an s_waitcnt vmcnt(0) at the join)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
+    auto epi_load_fast = [&](int z, EpiVals& ev) {
+      if (need_a) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)   // rows past Ho / channels past cout: a harmless in-range read of memory this workgroup owns or zero
+            ev.a[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, out_ok(z, true, r, i) ? xoff : 0x80000000u, out_ok(z, true, r, i) ? out_off(z, r, i) : 0u, 0));
+      }
+      if (need_r) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, out_ok(z, true, r, i) ? xoff : 0x80000000u, out_ok(z, true, r, i) ? out_off(z, r, i) : 0u, 0));
+      }
+    };
+    auto epilogue_fast = [&](int z, const f32x4 (&acc)[2], const EpiVals& ev) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int oy = y0 + 2 * wv + r;   // scalar
+        if (y0 + 2 * wv + r < Ho) {   // loop-invariant
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ev.a[r][i] = c0 == 0 ? bv[i] : 0.f;
-          ev.r[r][i] = 0.f;
-          if (oy < Ho && cog * 4 + i < cout) {
-            const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
-            if (c0 != 0) ev.a[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, xoff, so, 0));
-            if (last && res) ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, xoff, so, 0));
+          for (int i = 0; i < 4; ++i) {
+            if (cog * 4 + i < cout) {   // loop-invariant
+              float v = acc[r][i] + (need_a ? ev.a[r][i] : bv[i]);
+              if (last) {
+                if (need_r) v += ev.r[r][i];
+                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
+                const float vs = xin ? v : 0.f;
+                st1[i] += vs;
+                st2[i] += vs * vs;
+              }
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, out_off(z, r, i), 0);
+            }
           }
         }
       }
     };
+    auto epi_load = [&](int z, EpiVals& ev) {   // generic form: called for steps inside the chunk only
+      epi_load_fast(z, ev);
+    };
     // one output plane: multiply against the three ring planes, store
-    auto compute = [&](int z, const EpiVals& ev) {
+    auto mma = [&](int z, f32x4 (&acc)[2]) {
       const float* p0 = ring + ((z - pad) & 3) * WG_PLANE + lbase;
       const float* p1 = ring + ((z - pad + 1) & 3) * WG_PLANE + lbase;
       const float* p2 = ring + ((z - pad + 2) & 3) * WG_PLANE + lbase;
       // (six accumulation chains -- row x dz -- instead of two were measured: 20 % slower)
-      f32x4 acc[2];
       acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
       for (int ci = 0; ci < nci; ++ci) {
@@ -813,49 +852,45 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
                 acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[(dz * 3 + dy) * 3 + dx], pl[dy * WG_PX + dx], acc[r], 0, 0, 0);
           }
       }
-      // lane l holds out[co0 + i][row][x0 + l] in acc[row][i].  Buffer stores / loads: the lane part of the address is fixed
-      // for the whole kernel (x position; beyond the row: out of range = dropped / zero), row, plane and channel are scalar.
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int oy = y0 + 2 * wv + r;   // scalar
-        if (oy < Ho) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int oc = cog * 4 + i;
-            if (oc < cout) {
-              const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
-              float v = acc[r][i] + ev.a[r][i];
-              if (last) {  // last channel chunk: the sum is complete -> residual, activation, statistics
-                if (res) v += ev.r[r][i];
-                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
-                const float vs = xin ? v : 0.f;   // lanes beyond the row do not count
-                st1[i] += vs;
-                st2[i] += vs * vs;
-              }
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, so, 0);
-            }
-          }
-        }
-      }
     };
+    // lane l holds out[co0 + i][row][x0 + l] in acc[row][i].  Buffer stores / loads: the lane part of the address is fixed
+    // for the whole kernel (x position; beyond the row: out of range = dropped / zero), row, plane and channel are scalar.
     // Two planes are in flight at any time (register sets A / B): with a single plane the kernel was bound by the bytes it
     // kept outstanding (~22 KB per CU against a ~2 us loaded memory latency), not by the matrix pipe or LDS.
     // S register sets rotate: the plane parked after step z (ring slot of plane z - pad - 1, last read one barrier ago) was
     // requested S - 1 steps earlier, so S - 1 planes are in flight per workgroup at any time
     float nr[S][SK];
 #pragma unroll
-    for (int i = 0; i < S - 1; ++i)
-      if (zb + i + 1 < ze) stage_load(zb + i - pad + 3, nr[i]);
-    for (int z = zb; z < ze; z += S) {
+    for (int i = 0; i < S - 1; ++i) stage_load(zb + i - pad + 3, nr[i]);   // (generic form: a tiny volume ends here already)
+    // steady state: whole groups of S steps whose prefetched planes all lie inside the volume -- no per-step condition at all
+    int z = zb;
+    for (; z + S <= ze && (PADMODE == 1 || z + 2 * S + 1 - pad < Di); z += S) {
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int zz = z + s_;
+        EpiVals ev;
+        f32x4 acc[2];
+        epi_load_fast(zz, ev);
+        stage_load_fast(zz + S - 1 - pad + 3, nr[(s_ + S - 1) % S]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+        mma(zz, acc);
+        epilogue_fast(zz, acc, ev);
+        stage_store(zz - pad + 3, nr[s_]);
+        __syncthreads();
+      }
+    }
+    // the last steps of a chunk, generic form (planes past the volume are zero-filled, steps past the end skipped)
+    for (; z < ze; z += S) {
 #pragma unroll
       for (int s_ = 0; s_ < S; ++s_) {
         const int zz = z + s_;
         if (zz < ze) {  // workgroup-uniform
           EpiVals ev;
-          epi_load(zz, ev);
+          f32x4 acc[2];
+          epi_load_fast(zz, ev);
           if (zz + S < ze) stage_load(zz + S - 1 - pad + 3, nr[(s_ + S - 1) % S]);
-          __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
-          compute(zz, ev);
+          mma(zz, acc);
+          epilogue_fast(zz, acc, ev);
           if (zz + 1 < ze) stage_store(zz - pad + 3, nr[s_]);
           __syncthreads();
         }
@@ -937,8 +972,6 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
   constexpr unsigned OOB = 0x80000000u;
   const unsigned xoff = xin ? (unsigned)((x0 + lane) * 4) : OOB;
   const long ybase = ((long)b * cout + cog * 4) * ocs;
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, OOB, 0x00020000);
   float bv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) bv[i] = bias && cog * 4 + i < cout ? bias[cog * 4 + i] : 0.f;
@@ -958,10 +991,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
     }
     // one descriptor per channel quad (a quad's four planes stay inside the 2 GB a descriptor spans); the per-thread cell
     // offsets are fixed for the sweep, channel and plane go into the scalar offset
-    __amdgpu_buffer_rsrc_t xrs[NQ];
+    const float* xq[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      xrs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)(x + ((long)b * cin + min(c0 + 4 * q, cin - 1)) * ics), 0, OOB, 0x00020000);
+    for (int q = 0; q < NQ; ++q) xq[q] = x + ((long)b * cin + min(c0 + 4 * q, cin - 1)) * ics;
     unsigned soff[SKC];
 #pragma unroll
     for (int k = 0; k < SKC; ++k) {
@@ -977,21 +1009,33 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
       }
       soff[k] = ok ? (unsigned)(((long)yy * Wi + xx) * 4) : OOB;
     }
-    auto stage_load = [&](int zin, float (&v)[SKC][4 * NQ]) {
+    // steady-state form: plane inside the volume; a channel past cin re-reads the sweep's last channel (its weights are zero)
+    __amdgpu_buffer_rsrc_t xrs[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xrs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)xq[q], 0, OOB, 0x00020000);
+    auto stage_load_fast = [&](int zin, float (&v)[SKC][4 * NQ]) {
+      const int zz = PADMODE == 1 ? min(max(zin, 0), Di - 1) : zin;
+      const unsigned zp = (unsigned)((long)zz * Hi * Wi * 4);
+#pragma unroll
+      for (int c = 0; c < 4 * NQ; ++c) {
+        const int cc = min(c, nci - 1);   // scalar
+        const unsigned zs = zp + (unsigned)((long)(cc & 3) * ics * 4);
+#pragma unroll
+        for (int k = 0; k < SKC; ++k)
+          v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((cc >> 2) == 0 ? xrs[0] : xrs[NQ - 1], soff[k], zs, 0));
+      }
+    };
+    auto stage_load = [&](int zin, float (&v)[SKC][4 * NQ]) {   // generic form (see k_dconv3_mfma)
       int zz = zin;
       bool zok = (unsigned)zz < (unsigned)Di;
       if (PADMODE == 1) zz = min(max(zz, 0), Di - 1), zok = true;
+      if (zok) {  // workgroup-uniform
+        stage_load_fast(zz, v);
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4 * NQ; ++c) {
-        if (zok && c < nci) {  // workgroup-uniform
-          const unsigned zs = (unsigned)(((long)(c & 3) * ics + (long)zz * Hi * Wi) * 4);
+        for (int k = 0; k < SKC; ++k)
 #pragma unroll
-          for (int k = 0; k < SKC; ++k)
-            v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs[c >> 2], soff[k], zs, 0));
-        } else {
-#pragma unroll
-          for (int k = 0; k < SKC; ++k) v[k][c] = 0.f;
-        }
+          for (int c = 0; c < 4 * NQ; ++c) v[k][c] = 0.f;
       }
     };
     auto stage_store = [&](int zin, const float (&v)[SKC][4 * NQ]) {
@@ -1026,27 +1070,58 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
     // phase: one memory round trip hidden behind the MFMAs instead of eight exposed ones (a load per output row and channel,
     // each waited for on the spot), and the wait for it leaves the younger plane prefetches in flight.
     const bool last = c0 + 4 * NQ >= cin;
-    auto epi_load = [&](int z, EpiVals& ev) {
+    const bool need_a = c0 != 0, need_r = last && res != nullptr;   // sweep constants
+    // `ok` of an output row / channel of a step and its scalar offset
+    auto out_ok = [&](int z, bool valid, int r, int i) { return valid && y0 + 2 * wv + r < Ho && cog * 4 + i < cout; };
+    auto out_off = [&](int z, int r, int i) { return (unsigned)(((long)i * ocs + ((long)z * Ho + (y0 + 2 * wv + r)) * Wo) * 4); };
+    // steady-state form: no step / row conditions beyond the loop-invariant ones, and NO write to ev on the paths that do not
+    // load (a v_mov into a register some other path loads into costs an s_waitcnt vmcnt(0) at the join)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
+    auto epi_load_fast = [&](int z, EpiVals& ev) {
+      if (need_a) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)   // rows past Ho / channels past cout: a harmless in-range read of memory this workgroup owns or zero
+            ev.a[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, out_ok(z, true, r, i) ? xoff : 0x80000000u, out_ok(z, true, r, i) ? out_off(z, r, i) : 0u, 0));
+      }
+      if (need_r) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, out_ok(z, true, r, i) ? xoff : 0x80000000u, out_ok(z, true, r, i) ? out_off(z, r, i) : 0u, 0));
+      }
+    };
+    auto epilogue_fast = [&](int z, const f32x4 (&acc)[2], const EpiVals& ev) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const int oy = y0 + 2 * wv + r;   // scalar
+        if (y0 + 2 * wv + r < Ho) {   // loop-invariant
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          ev.a[r][i] = c0 == 0 ? bv[i] : 0.f;
-          ev.r[r][i] = 0.f;
-          if (oy < Ho && cog * 4 + i < cout) {
-            const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
-            if (c0 != 0) ev.a[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, xoff, so, 0));
-            if (last && res) ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, xoff, so, 0));
+          for (int i = 0; i < 4; ++i) {
+            if (cog * 4 + i < cout) {   // loop-invariant
+              float v = acc[r][i] + (need_a ? ev.a[r][i] : bv[i]);
+              if (last) {
+                if (need_r) v += ev.r[r][i];
+                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
+                const float vs = xin ? v : 0.f;
+                st1[i] += vs;
+                st2[i] += vs * vs;
+              }
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, out_off(z, r, i), 0);
+            }
           }
         }
       }
     };
-    auto compute = [&](int z, const EpiVals& ev) {
+    auto epi_load = [&](int z, EpiVals& ev) {   // generic form: called for steps inside the chunk only
+      epi_load_fast(z, ev);
+    };
+    auto mma = [&](int z, f32x4 (&acc)[2]) {
       const ds16x4* p0 = ring + ((z - pad) & 3) * SLOT + lbase;
       const ds16x4* p1 = ring + ((z - pad + 1) & 3) * SLOT + lbase;
       const ds16x4* p2 = ring + ((z - pad + 2) & 3) * SLOT + lbase;
-      f32x4 acc[2];
       acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
@@ -1061,43 +1136,39 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
               for (int r = 0; r < 2; ++r)
                 acc[r] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wr[q][(dz * 3 + dy) * 3 + dx], pl[(r + dy) * WG_PX + dx], acc[r], 0, 0, 0);
         }
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int oy = y0 + 2 * wv + r;   // scalar
-        if (oy < Ho) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int oc = cog * 4 + i;
-            if (oc < cout) {
-              const unsigned so = (unsigned)(((long)i * ocs + ((long)z * Ho + oy) * Wo) * 4);
-              float v = acc[r][i] + ev.a[r][i];
-              if (last) {  // last channel chunk: the sum is complete -> residual, activation, statistics
-                if (res) v += ev.r[r][i];
-                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
-                const float vs = xin ? v : 0.f;
-                st1[i] += vs;
-                st2[i] += vs * vs;
-              }
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, so, 0);
-            }
-          }
-        }
-      }
     };
-    float nr[S][SKC][4 * NQ];   // S rotating register sets: S - 1 planes in flight (see k_dconv3_mfma)
+    float nr[S][SKC][4 * NQ];
 #pragma unroll
-    for (int i = 0; i < S - 1; ++i)
-      if (zb + i + 1 < ze) stage_load(zb + i - pad + 3, nr[i]);
-    for (int z = zb; z < ze; z += S) {
+    for (int i = 0; i < S - 1; ++i) stage_load(zb + i - pad + 3, nr[i]);   // (generic form: a tiny volume ends here already)
+    // steady state: whole groups of S steps whose prefetched planes all lie inside the volume -- no per-step condition at all
+    int z = zb;
+    for (; z + S <= ze && (PADMODE == 1 || z + 2 * S + 1 - pad < Di); z += S) {
+#pragma unroll
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int zz = z + s_;
+        EpiVals ev;
+        f32x4 acc[2];
+        epi_load_fast(zz, ev);
+        stage_load_fast(zz + S - 1 - pad + 3, nr[(s_ + S - 1) % S]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+        mma(zz, acc);
+        epilogue_fast(zz, acc, ev);
+        stage_store(zz - pad + 3, nr[s_]);
+        __syncthreads();
+      }
+    }
+    // the last steps of a chunk, generic form (planes past the volume are zero-filled, steps past the end skipped)
+    for (; z < ze; z += S) {
 #pragma unroll
       for (int s_ = 0; s_ < S; ++s_) {
         const int zz = z + s_;
         if (zz < ze) {  // workgroup-uniform
           EpiVals ev;
-          epi_load(zz, ev);
+          f32x4 acc[2];
+          epi_load_fast(zz, ev);
           if (zz + S < ze) stage_load(zz + S - 1 - pad + 3, nr[(s_ + S - 1) % S]);
-          __builtin_amdgcn_sched_barrier(0);
-          compute(zz, ev);
+          mma(zz, acc);
+          epilogue_fast(zz, acc, ev);
           if (zz + 1 < ze) stage_store(zz - pad + 3, nr[s_]);
           __syncthreads();
         }
