@@ -103,14 +103,17 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   }
   // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
   // (stage_store) after it, so the global-memory latency hides behind the MFMAs
-  auto stage_load = [&](int zp, float (&v)[SK]) {
-    int zz = zp;
-    bool zok = (unsigned)zz < (unsigned)D;
-    if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
-    if (zok) {
-      const unsigned zs = (unsigned)((long)zz * H * W * 4);
+  // steady-state form (plane inside the volume) and generic form: see k_dconv3_mfma -- a zero-fill on the other side of a
+  // branch makes the compiler wait for the prefetch in flight (vmcnt(0)) at the join
+  auto stage_load_fast = [&](int zp, float (&v)[SK]) {
+    const int zz = PADMODE == 1 ? min(max(zp, 0), D - 1) : zp;
+    const unsigned zs = (unsigned)((long)zz * H * W * 4);
 #pragma unroll
-      for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+    for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+  };
+  auto stage_load = [&](int zp, float (&v)[SK]) {
+    if (PADMODE == 1 || (unsigned)zp < (unsigned)D) {
+      stage_load_fast(zp, v);
     } else {
 #pragma unroll
       for (int k = 0; k < SK; ++k) v[k] = 0.f;
@@ -150,6 +153,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
     const int xv = x0 + qx * 16 + blk;
     goff[qx] = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;
   }
+  unsigned goffr[8];   // the same with the row's validity folded in: the steady-state loads carry no condition
+#pragma unroll
+  for (int rq = 0; rq < 8; ++rq) goffr[rq] = y0 + 2 * wv + (rq >> 2) < H ? goff[rq & 3] : OOB;
+  auto g_load_fast = [&](int z, float (&gv)[8]) {
+#pragma unroll
+    for (int rq = 0; rq < 8; ++rq)
+      gv[rq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, goffr[rq], (unsigned)(((long)z * H + y0 + 2 * wv + (rq >> 2)) * W * 4), 0));
+  };
   auto g_load = [&](int z, float (&gv)[8]) {
 #pragma unroll
     for (int rq = 0; rq < 8; ++rq) {
@@ -187,7 +198,23 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   float nA[SK], nB[SK], gA[8], gB[8];
   if (zb < ze) g_load(zb, gA);
   if (zb + 1 < ze) stage_load(zb + 2, nA);
-  for (int z = zb; z < ze; z += 2) {
+  // steady state: both steps of the pair, their g rows and their prefetched planes lie inside the chunk / the volume
+  int z = zb;
+  for (; z + 3 < ze && (PADMODE == 1 || z + 4 < D); z += 2) {
+    stage_load_fast(z + 3, nB);
+    g_load_fast(z + 1, gB);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+    multiply(z, gA);
+    stage_store(z + 2, nA);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
+    __syncthreads();
+    stage_load_fast(z + 4, nA);
+    g_load_fast(z + 2, gA);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(z + 1, gB);
+    stage_store(z + 3, nB);
+    __syncthreads();
+  }
+  for (; z < ze; z += 2) {   // chunk end, generic form
     if (z + 2 < ze) stage_load(z + 3, nB);
     g_load(z + 1, gB);
     __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
@@ -301,16 +328,17 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __res
       soff[k][m] = ok ? (unsigned)(((long)c * cs + (long)yy * W + xx) * 4) : OOB;
     }
   }
+  auto stage_load_fast = [&](int zp, float (&v)[SKI][4]) {   // steady-state form: plane inside the volume
+    const int zz = PADMODE == 1 ? min(max(zp, 0), D - 1) : zp;
+    const unsigned zs = (unsigned)((long)zz * H * W * 4);
+#pragma unroll
+    for (int k = 0; k < SKI; ++k)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[k][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k][m], zs, 0));
+  };
   auto stage_load = [&](int zp, float (&v)[SKI][4]) {
-    int zz = zp;
-    bool zok = (unsigned)zz < (unsigned)D;
-    if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
-    if (zok) {
-      const unsigned zs = (unsigned)((long)zz * H * W * 4);
-#pragma unroll
-      for (int k = 0; k < SKI; ++k)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) v[k][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k][m], zs, 0));
+    if (PADMODE == 1 || (unsigned)zp < (unsigned)D) {
+      stage_load_fast(zp, v);
     } else {
 #pragma unroll
       for (int k = 0; k < SKI; ++k)
@@ -347,6 +375,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __res
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int xv = x0 + 4 * blk;
   const unsigned goff = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;   // W % 4 == 0: the four voxels are in or out together
+  unsigned goffr[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) goffr[r] = y0 + 2 * wv + r < H ? goff : OOB;
+  auto g_load_fast = [&](int z, float4 (&gv)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      gv[r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, goffr[r], (unsigned)(((long)z * H + y0 + 2 * wv + r) * W * 4), 0));
+  };
   auto g_load = [&](int z, float4 (&gv)[2]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -386,7 +422,23 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __res
   float4 gA[2], gB[2];
   if (zb < ze) g_load(zb, gA);
   if (zb + 1 < ze) stage_load(zb + 2, nA);
-  for (int z = zb; z < ze; z += 2) {
+  // steady state: both steps of the pair, their g rows and their prefetched planes lie inside the chunk / the volume
+  int z = zb;
+  for (; z + 3 < ze && (PADMODE == 1 || z + 4 < D); z += 2) {
+    stage_load_fast(z + 3, nB);
+    g_load_fast(z + 1, gB);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+    multiply(z, gA);
+    stage_store(z + 2, nA);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
+    __syncthreads();
+    stage_load_fast(z + 4, nA);
+    g_load_fast(z + 2, gA);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(z + 1, gB);
+    stage_store(z + 3, nB);
+    __syncthreads();
+  }
+  for (; z < ze; z += 2) {   // chunk end, generic form
     if (z + 2 < ze) stage_load(z + 3, nB);
     g_load(z + 1, gB);
     __builtin_amdgcn_sched_barrier(0);
@@ -481,14 +533,17 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   }
   // a plane is fetched into registers (stage_load) before the multiply phase and parked in its ring slot
   // (stage_store) after it, so the global-memory latency hides behind the MFMAs
-  auto stage_load = [&](int zp, float (&v)[SK]) {
-    int zz = zp;
-    bool zok = (unsigned)zz < (unsigned)D;
-    if (PADMODE == 1) zz = min(max(zz, 0), D - 1), zok = true;
-    if (zok) {
-      const unsigned zs = (unsigned)((long)zz * H * W * 4);
+  // steady-state form (plane inside the volume) and generic form: see k_dconv3_mfma -- a zero-fill on the other side of a
+  // branch makes the compiler wait for the prefetch in flight (vmcnt(0)) at the join
+  auto stage_load_fast = [&](int zp, float (&v)[SK]) {
+    const int zz = PADMODE == 1 ? min(max(zp, 0), D - 1) : zp;
+    const unsigned zs = (unsigned)((long)zz * H * W * 4);
 #pragma unroll
-      for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+    for (int k = 0; k < SK; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, soff[k], zs, 0));
+  };
+  auto stage_load = [&](int zp, float (&v)[SK]) {
+    if (PADMODE == 1 || (unsigned)zp < (unsigned)D) {
+      stage_load_fast(zp, v);
     } else {
 #pragma unroll
       for (int k = 0; k < SK; ++k) v[k] = 0.f;
@@ -535,6 +590,14 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
     const int xv = x0 + qx * 16 + blk;
     goff[qx] = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;
   }
+  unsigned goffr[8];   // the same with the row's validity folded in: the steady-state loads carry no condition
+#pragma unroll
+  for (int rq = 0; rq < 8; ++rq) goffr[rq] = y0 + 2 * wv + (rq >> 2) < H ? goff[rq & 3] : OOB;
+  auto g_load_fast = [&](int z, float (&gv)[8]) {
+#pragma unroll
+    for (int rq = 0; rq < 8; ++rq)
+      gv[rq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, goffr[rq], (unsigned)(((long)z * H + y0 + 2 * wv + (rq >> 2)) * W * 4), 0));
+  };
   auto g_load = [&](int z, float (&gv)[8]) {
 #pragma unroll
     for (int rq = 0; rq < 8; ++rq) {
@@ -565,7 +628,23 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   float nA[SK], nB[SK], gA[8], gB[8];  // see k_dconv3_wgrad_mfma: g one step ahead, x planes two steps ahead
   if (zb < ze) g_load(zb, gA);
   if (zb + 1 < ze) stage_load(zb + 2, nA);
-  for (int z = zb; z < ze; z += 2) {
+  // steady state: both steps of the pair, their g rows and their prefetched planes lie inside the chunk / the volume
+  int z = zb;
+  for (; z + 3 < ze && (PADMODE == 1 || z + 4 < D); z += 2) {
+    stage_load_fast(z + 3, nB);
+    g_load_fast(z + 1, gB);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the multiply phase (the scheduler would sink them)
+    multiply(z, gA);
+    stage_store(z + 2, nA);  // slot (z+2)&3 was last read as plane z-2: its readers passed the previous barrier
+    __syncthreads();
+    stage_load_fast(z + 4, nA);
+    g_load_fast(z + 2, gA);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(z + 1, gB);
+    stage_store(z + 3, nB);
+    __syncthreads();
+  }
+  for (; z < ze; z += 2) {   // chunk end, generic form
     if (z + 2 < ze) stage_load(z + 3, nB);
     g_load(z + 1, gB);
     __builtin_amdgcn_sched_barrier(0);
