@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_f16(const float* __restrict__
 // faces.  y rows are fixed per thread (weights folded once), z planes per step (centre-plane weights summed in a uniform
 // branch), x ends are two corrections per plane for the lanes that own x = 0 / x = W - 1.  Replaces the correlation on the
 // (D+2)(H+2)(W+2) halo domain + k_fold_replicate (a second pass over a larger volume).
-template <int PADMODE, bool FOLD = false>
+template <int PADMODE, bool FOLD = false, bool ASYNC = false>
 __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
                                                     float* __restrict__ y, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
@@ -1678,6 +1678,91 @@ __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x,
   // Five plane buffers in rotation: three under the stencil, two in flight.  With the next plane requested only when the
   // current one was done, a wave kept 3 KB outstanding and the kernel ran at the memory LATENCY (1.7 TB/s).
   float p0[3][6], p1[3][6], p2[3][6], p3[3][6], p4[3][6];
+  if constexpr (ASYNC) {   // the launcher's promise: rows of whole quads (Wi % 4 == 0) and pad == 1
+    // Asynchronous form (rows of whole quads, pad 1: every FeatureExtraction layer).  load_plane above post-processes a plane
+    // (lane exchange, border selects) right after requesting it, i.e. it WAITS for it, and its conditional loads / zero
+    // fills make the compiler copy plane registers at the joins (s_waitcnt vmcnt(0) again): the "two planes in flight" never
+    // were.  Here a request is three unconditional buffer loads per row -- the lane's own quad, and one word each for the
+    // first / last lane of the row, every other lane carrying an out-of-range offset (returns 0, moves nothing) -- into the
+    // RAW image {own.x .. own.w, left, right}; the image is turned into the 6-column window (finalize) two steps later,
+    // right before the plane's first use.  Rows outside the volume are read clamped and their WEIGHTS zeroed (same
+    // products); planes outside it go through a descriptor of zero records (chunk ends only, generic loop below).
+    constexpr unsigned OOB = 0x80000000u;
+    const long plane_elems = (long)Hi * Wi;
+    const bool first = tx == 0, lastl = tx == 63 || ox + 4 >= Wi;
+    const unsigned vo_own = own_ok ? (unsigned)(ox * 4) : OOB;
+    const unsigned vo_l = (first && (PADMODE == 1 || ox >= 1)) ? (unsigned)(max(ox - 1, 0) * 4) : OOB;
+    const unsigned vo_r = (lastl && (PADMODE == 1 || ox + 4 < Wi)) ? (unsigned)(min(ox + 4, Wi - 1) * 4) : OOB;
+    if (PADMODE == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (!rok[r]) {   // wave-uniform: the row lies outside the volume -> its taps contribute nothing
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) wt[dz * 9 + r * 3 + dx] = 0.f;
+        }
+    }
+    const int ro0 = __builtin_amdgcn_readfirstlane(roff[0]), ro1 = __builtin_amdgcn_readfirstlane(roff[1]),
+              ro2 = __builtin_amdgcn_readfirstlane(roff[2]);   // a wave is one row: scalar
+    auto request = [&](int zin, bool zok, float (&v)[3][6]) {   // zok: scalar
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, zok ? OOB : 0u, 0x00020000);
+      const long zp = (long)min(max(zin, 0), Di - 1) * plane_elems;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const unsigned so = (unsigned)((zp + (r == 0 ? ro0 : r == 1 ? ro1 : ro2)) * 4);
+        const float4 own = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo_own, so, 0));
+        v[r][0] = own.x; v[r][1] = own.y; v[r][2] = own.z; v[r][3] = own.w;
+        v[r][4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_l, so, 0));
+        v[r][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_r, so, 0));
+      }
+    };
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+    auto request_fast = [&](int zin, float (&v)[3][6]) {   // plane inside the volume (PADMODE 1: clamped into it)
+      const long zp = (long)(PADMODE == 1 ? min(max(zin, 0), Di - 1) : zin) * plane_elems;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const unsigned so = (unsigned)((zp + (r == 0 ? ro0 : r == 1 ? ro1 : ro2)) * 4);
+        const float4 own = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo_own, so, 0));
+        v[r][0] = own.x; v[r][1] = own.y; v[r][2] = own.z; v[r][3] = own.w;
+        v[r][4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo_l, so, 0));
+        v[r][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo_r, so, 0));
+      }
+    };
+    auto finalize = [&](float (&v)[3][6]) {   // raw image -> window columns ox-1 .. ox+4
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float ox_ = v[r][0], oy_ = v[r][1], oz_ = v[r][2], ow_ = v[r][3];
+        const float lw = dpp_mov<0x138>(ow_), rx = dpp_mov<0x130>(ox_);   // lane i reads lane i-1 / i+1
+        const float l = first ? v[r][4] : lw, rr = lastl ? v[r][5] : rx;
+        v[r][0] = l; v[r][1] = ox_; v[r][2] = oy_; v[r][3] = oz_; v[r][4] = ow_; v[r][5] = rr;
+      }
+    };
+    auto zin_ok = [&](int zin) { return PADMODE == 1 || (unsigned)zin < (unsigned)Di; };
+    request(zb - 1, zin_ok(zb - 1), p0);
+    request(zb, zin_ok(zb), p1);
+    request(zb + 1, zin_ok(zb + 1), p2);
+    request(zb + 2, zin_ok(zb + 2), p3);
+    finalize(p0);
+    finalize(p1);
+    int z = zb;
+    // steady state: groups of five steps inside the chunk whose requested planes (up to z + 7) lie inside the volume
+    for (; z + 5 <= ze && (PADMODE == 1 || z + 7 < Di); z += 5) {
+      request_fast(z + 3, p4); finalize(p2); emit(z, p0, p1, p2);
+      request_fast(z + 4, p0); finalize(p3); emit(z + 1, p1, p2, p3);
+      request_fast(z + 5, p1); finalize(p4); emit(z + 2, p2, p3, p4);
+      request_fast(z + 6, p2); finalize(p0); emit(z + 3, p3, p4, p0);
+      request_fast(z + 7, p3); finalize(p1); emit(z + 4, p4, p0, p1);
+    }
+    for (; z < ze; z += 5) {   // chunk end, generic form
+      request(z + 3, zin_ok(z + 3), p4); finalize(p2); emit(z, p0, p1, p2);
+      if (z + 1 < ze) { request(z + 4, zin_ok(z + 4), p0); finalize(p3); emit(z + 1, p1, p2, p3); }
+      if (z + 2 < ze) { request(z + 5, zin_ok(z + 5), p1); finalize(p4); emit(z + 2, p2, p3, p4); }
+      if (z + 3 < ze) { request(z + 6, zin_ok(z + 6), p2); finalize(p0); emit(z + 3, p3, p4, p0); }
+      if (z + 4 < ze) { request(z + 7, zin_ok(z + 7), p3); finalize(p1); emit(z + 4, p4, p0, p1); }
+    }
+    return;
+  }
   load_plane(zb - pad, p0);
   load_plane(zb - pad + 1, p1);
   load_plane(zb - pad + 2, p2);
@@ -1715,6 +1800,13 @@ static bool use_mfma_c1() {  // A/B switch: single-channel layers on the matrix-
   }();
   return v;
 }
+static bool stencil_async() {  // A/B switch: HP_STENCIL_ASYNC=0 keeps the single-channel stencil on its synchronous plane loads
+  static const bool v = [] {
+    const char* e = getenv("HP_STENCIL_ASYNC");
+    return !e || atoi(e) != 0;
+  }();
+  return v;
+}
 static int dconv_sets(int dflt) {  // A/B switch: planes in flight per workgroup + 1 (register sets of the z walk)
   static const int v = [] {
     const char* e = getenv("HP_DCONV_SETS");
@@ -1743,10 +1835,15 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
     static const int zc_env = getenv("HP_STENCIL_ZC") ? atoi(getenv("HP_STENCIL_ZC")) : 0;
     const int zc = zc_env > 0 ? zc_env : (Do >= 256 ? 64 : std::max(8, (Do + 3) / 4));
     dim3 g1((unsigned)((Wo + 255) / 256), (unsigned)((Ho + 3) / 4), (unsigned)(B * ((Do + zc - 1) / zc)));
-    if (padmode)
-      hipLaunchKernelGGL((k_stencil_c1<1>), g1, dim3(256), 0, st, x, w, bias, res, y, Di, Hi, Wi, Do, Ho, Wo, pad, flip, zc, slope);
-    else
-      hipLaunchKernelGGL((k_stencil_c1<0>), g1, dim3(256), 0, st, x, w, bias, res, y, Di, Hi, Wi, Do, Ho, Wo, pad, flip, zc, slope);
+    const bool async = (Wi & 3) == 0 && pad == 1 && stencil_async();
+#define HP_ST_LAUNCH(PM, AS) \
+  hipLaunchKernelGGL((k_stencil_c1<PM, false, AS>), g1, dim3(256), 0, st, x, w, bias, res, y, Di, Hi, Wi, Do, Ho, Wo, pad, flip, zc, slope)
+    if (padmode) {
+      if (async) HP_ST_LAUNCH(1, true); else HP_ST_LAUNCH(1, false);
+    } else {
+      if (async) HP_ST_LAUNCH(0, true); else HP_ST_LAUNCH(0, false);
+    }
+#undef HP_ST_LAUNCH
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
@@ -1871,8 +1968,12 @@ extern "C" int hp_dconv3_backward_data_p(const float* gy, const float* w, float*
     static const int zc_env = getenv("HP_STENCIL_ZC") ? atoi(getenv("HP_STENCIL_ZC")) : 0;
     const int zc = zc_env > 0 ? zc_env : (D >= 256 ? 64 : std::max(8, (D + 3) / 4));
     dim3 g1((unsigned)((W + 255) / 256), (unsigned)((H + 3) / 4), (unsigned)(B * ((D + zc - 1) / zc)));
-    hipLaunchKernelGGL((k_stencil_c1<0, true>), g1, dim3(256), 0, st, gy, w, (const float*)nullptr, (const float*)nullptr, gx, D, H, W, D, H,
-                       W, 1, 1, zc, 1.0f);
+    if ((W & 3) == 0 && stencil_async())
+      hipLaunchKernelGGL((k_stencil_c1<0, true, true>), g1, dim3(256), 0, st, gy, w, (const float*)nullptr, (const float*)nullptr, gx, D, H,
+                         W, D, H, W, 1, 1, zc, 1.0f);
+    else
+      hipLaunchKernelGGL((k_stencil_c1<0, true, false>), g1, dim3(256), 0, st, gy, w, (const float*)nullptr, (const float*)nullptr, gx, D, H,
+                         W, D, H, W, 1, 1, zc, 1.0f);
     HP_CHECK_HIP(hipGetLastError());
     return HP_OK;
   }
