@@ -651,19 +651,42 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
 #pragma unroll
         for (int j = 0; j < C::TN; ++j) smem[rl * LDO + wn * C::TN * 32 + j * 32 + (lane & 31)] = acc[h][j][r];
       }
+      // The slab's addend rows (and their sign masks) are requested TOGETHER, here -- acc[h] is dead, its registers hold them --
+      // and consumed after the barrier: one memory round trip per 32-row slab.  Requested inside the store loop below, each
+      // load was waited for on the spot (16 exposed round trips per tile: the 1^3 data gradients with K = 64 .. 256 spent
+      // more time there than in their MFMAs).
+      constexpr int K2 = (64 * Q) / CT;
+      float4 avb[K2];
+      unsigned mkb[K2];
+      if (fast && addend) {
+#pragma unroll
+        for (int k2 = 0; k2 < K2; ++k2) {
+          const int rowc = k2 * RPK;
+          const unsigned so = (unsigned)(((rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31)) * g.Nout * 4);
+          avb[k2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, vo, so, 0));
+        }
+        if (amask) {
+#pragma unroll
+          for (int k2 = 0; k2 < K2; ++k2) {
+            const int rowc = k2 * RPK;
+            const unsigned so = (unsigned)(((rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31)) * g.Nout * 4);
+            mkb[k2] = __builtin_amdgcn_raw_buffer_load_b8(mrs, vo >> 4, so >> 4, 0);
+          }
+        }
+      }
       __syncthreads();
       if (fast) {
 #pragma unroll
-        for (int k2 = 0; k2 < (64 * Q) / CT; ++k2) {
+        for (int k2 = 0; k2 < K2; ++k2) {
           const int rowc = k2 * RPK;                                             // staging row = r_l + rowc
           const int trow_c = (rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31);  // tile row = r_l + trow_c (RPK divides 32)
           const unsigned so = (unsigned)(trow_c * g.Nout * 4);
           float4 v = *(const float4*)(smem + (r_l + rowc) * LDO + 4 * q_l);
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           if (addend) {
-            float4 av = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, vo, so, 0));
+            float4 av = avb[k2];
             if (amask) {
-              const unsigned mk = __builtin_amdgcn_raw_buffer_load_b8(mrs, vo >> 4, so >> 4, 0);
+              const unsigned mk = mkb[k2];
               av.x = (mk & 1u) ? av.x : 0.f;
               av.y = (mk & 2u) ? av.y : 0.f;
               av.z = (mk & 4u) ? av.z : 0.f;
