@@ -2291,16 +2291,25 @@ __global__ __launch_bounds__(256) void k_stem_fwd_mfma(const float* __restrict__
     soff[k] = ok ? yy * W + xx : 0;
     smask |= ok ? (1u << k) : 0u;
   }
-  auto stage = [&](int zin) {
-    float* dst = ring + (zin & 7) * SF_PLANE + tid;
+  // a plane is REQUESTED before a step's multiply phase and parked in its ring slot after it (the slot of plane z - 4 is free
+  // during step z): with one workgroup per CU (153 KB of LDS) nothing else hides the latency of a load that is waited for
+  // on the spot -- the synchronous form cost a full memory round trip per 5 us step
+  auto stage_load = [&](int zin, float (&v)[SK]) {
     const bool zok = (unsigned)zin < (unsigned)D;
     const float* src = xb + (long)(zok ? zin : 0) * H * W;
-    float v[SK];
 #pragma unroll
     for (int k = 0; k < SK; ++k) v[k] = (zok && ((smask >> k) & 1u)) ? src[soff[k]] : 0.f;
+  };
+  auto stage_store = [&](int zin, const float (&v)[SK]) {
+    float* dst = ring + (zin & 7) * SF_PLANE + tid;
 #pragma unroll
     for (int k = 0; k < SK; ++k)
       if (tid + 256 * k < SF_PLANE) dst[256 * k] = v[k];
+  };
+  auto stage = [&](int zin) {
+    float v[SK];
+    stage_load(zin, v);
+    stage_store(zin, v);
   };
   if (zb < ze)
     for (int zin = zb - 3; zin <= zb + 3; ++zin) stage(zin);
@@ -2309,7 +2318,9 @@ __global__ __launch_bounds__(256) void k_stem_fwd_mfma(const float* __restrict__
   float* const ot = otile + wave * (64 * 33);
   float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};  // this lane's channels 32 hh + (lane & 31), lanes < 32 only
   for (int z = zb; z < ze; ++z) {
-    if (z + 1 < ze) stage(z + 4);  // replaces plane z - 4, last read one barrier ago
+    float nv[SK];
+    if (z + 1 < ze) stage_load(z + 4, nv);  // replaces plane z - 4, last read one barrier ago
+    __builtin_amdgcn_sched_barrier(0);      // keep the request ahead of the multiply phase
     f32x4c acc[2][16];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -2378,6 +2389,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd_mfma(const float* __restrict__
         }
       }
     }
+    if (z + 1 < ze) stage_store(z + 4, nv);
     __syncthreads();
   }
   if (stats && lane < 32) {
