@@ -327,40 +327,55 @@ __global__ __launch_bounds__(ST) void k_attention_patch_h16(const float* __restr
   const int qi = blockIdx.x * 128 + wave * 32 + col;
   const bool qvalid = qi < n;
   const int qtok = nj + f * n + qi;
-  // B operand of S^T: this lane's query, d = 16 s + 8 half .. + 7
+  // B operand of S^T: this lane's query, d = 16 s + 8 half .. + 7.  Scores are kept in the log2 domain (the query carries
+  // log2 e): exp(s - m) = exp2(s' - m') is then ONE v_exp_f32 per score instead of a multiply + v_exp_f32.
+  constexpr float LOG2E = 1.4426950408889634f;
   bf16x8s qf[2];
+  {
+    // four 16-byte loads in flight (a query row past n re-reads the last one: its result is not stored); the element-wise
+    // conditional form compiled to 16 loads, each waited for on the spot
+    const float* qrow = Qb + (long)(nj + f * n + min(qi, n - 1)) * DH + 8 * half;
+    float4 q4[4];
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
+    for (int u = 0; u < 4; ++u) q4[u] = *(const float4*)(qrow + 16 * (u >> 1) + 4 * (u & 1));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[s2][j] = (H)(qvalid ? Qb[(long)qtok * DH + 16 * s2 + 8 * half + j] : 0.f);
+    for (int u = 0; u < 4; ++u) {
+      qf[u >> 1][4 * (u & 1) + 0] = (H)(q4[u].x * LOG2E);
+      qf[u >> 1][4 * (u & 1) + 1] = (H)(q4[u].y * LOG2E);
+      qf[u >> 1][4 * (u & 1) + 2] = (H)(q4[u].z * LOG2E);
+      qf[u >> 1][4 * (u & 1) + 3] = (H)(q4[u].w * LOG2E);
+    }
+  }
 
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
   float m = -FLT_MAX, l = 0.f;
   const int ntiles = (nkeys + 31) / 32;
+  // With 32-wide heads this kernel is bound by the soft-max's vector work, not by the matrix cores (4 MFMAs = 128 cycles per
+  // 32-key tile against ~900 cycles of compare / exp / scale per wave), so that work is what is trimmed: key masking only in
+  // the ragged last tile, the running-maximum rescale of the 16 accumulators only when some query's maximum actually grew
+  // (wave-uniform test; after the first tiles it rarely does), and the next tile's K / V rows requested BEFORE the current
+  // tile's arithmetic (they used to be loaded and waited for, one by one, between the two barriers).
+  typedef __attribute__((ext_vector_type(4))) H h4;
+  const int kr = tid >> 3, dq = (tid & 7) * 4;   // 32 keys x 8 channel quads = one float4 of K and of V per thread
+  const int slot = (kr >> 4) * 16 + ((kr >> 2) & 1) * 8 + (kr & 3) + 4 * ((kr >> 3) & 1);
+  auto request = [&](int tile, float4& kv, float4& vv) {
+    const int kj = min(tile * 32 + kr, nkeys - 1);   // rows past the last key: any finite row (their scores are masked)
+    const int tok = kj < nj ? kj : nj + f * n + (kj - nj);
+    kv = *(const float4*)(Kb + (long)tok * DH + dq);
+    vv = *(const float4*)(Vb + (long)tok * DH + dq);
+  };
+  float4 kv, vv;
+  request(0, kv, vv);
   for (int tile = 0; tile < ntiles; ++tile) {
     __syncthreads();
-    {  // 32 keys x 8 channel quads = one float4 of K and of V per thread
-      const int kr = tid >> 3, d = (tid & 7) * 4;
-      const int kj = tile * 32 + kr;
-      float4 kv = make_float4(0, 0, 0, 0), vv = kv;
-      if (kj < nkeys) {
-        const int tok = kj < nj ? kj : nj + f * n + (kj - nj);
-        kv = *(const float4*)(Kb + (long)tok * DH + d);
-        vv = *(const float4*)(Vb + (long)tok * DH + d);
-      }
-      H* kd = Kh + kr * LDB + d;
-      kd[0] = (H)kv.x;
-      kd[1] = (H)kv.y;
-      kd[2] = (H)kv.z;
-      kd[3] = (H)kv.w;
-      const int slot = (kr >> 4) * 16 + ((kr >> 2) & 1) * 8 + (kr & 3) + 4 * ((kr >> 3) & 1);
-      Vt[(d + 0) * LDB + slot] = (H)vv.x;
-      Vt[(d + 1) * LDB + slot] = (H)vv.y;
-      Vt[(d + 2) * LDB + slot] = (H)vv.z;
-      Vt[(d + 3) * LDB + slot] = (H)vv.w;
-    }
+    *(h4*)(Kh + kr * LDB + dq) = (h4){(H)kv.x, (H)kv.y, (H)kv.z, (H)kv.w};
+    Vt[(dq + 0) * LDB + slot] = (H)vv.x;
+    Vt[(dq + 1) * LDB + slot] = (H)vv.y;
+    Vt[(dq + 2) * LDB + slot] = (H)vv.z;
+    Vt[(dq + 3) * LDB + slot] = (H)vv.w;
+    if (tile + 1 < ntiles) request(tile + 1, kv, vv);
     __syncthreads();
     f32x16 sacc;
 #pragma unroll
@@ -368,28 +383,34 @@ __global__ __launch_bounds__(ST) void k_attention_patch_h16(const float* __restr
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
       sacc = mfma_h16<H>(*(const bf16x8s*)(Kh + col * LDB + 16 * s2 + 8 * half), qf[s2], sacc);
-    float tm = -FLT_MAX;
+    const bool ragged = tile == ntiles - 1 && (nkeys & 31) != 0;   // workgroup-uniform
+    if (ragged) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (key >= nkeys) sacc[r] = -FLT_MAX;
-      tm = fmaxf(tm, sacc[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (key >= nkeys) sacc[r] = -FLT_MAX;
+      }
     }
+    float tm = fmaxf(fmaxf(fmaxf(sacc[0], sacc[1]), fmaxf(sacc[2], sacc[3])), fmaxf(fmaxf(sacc[4], sacc[5]), fmaxf(sacc[6], sacc[7])));
+    tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(sacc[8], sacc[9]), fmaxf(sacc[10], sacc[11])), fmaxf(fmaxf(sacc[12], sacc[13]), fmaxf(sacc[14], sacc[15]))));
     tm = fmaxf(tm, __shfl_xor(tm, 32));
-    const float mn = fmaxf(m, tm);
-    const float alpha = __expf(m - mn);
+    if (__builtin_amdgcn_ballot_w64(tm > m) != 0ull) {   // some query of this wave has a new maximum: rescale
+      const float mn = fmaxf(m, tm);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      l *= alpha;
+      m = mn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pr = sacc[r] > -FLT_MAX ? __expf(sacc[r] - mn) : 0.f;
+      const float pr = __builtin_amdgcn_exp2f(sacc[r] - m);   // masked keys: exp2(-huge) = 0
       sacc[r] = pr;
       ps += pr;
     }
     ps += __shfl_xor(ps, 32);
-    l = l * alpha + ps;
-    m = mn;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    l += ps;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       bf16x8s pf;
