@@ -228,7 +228,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   constexpr int NPL = NP > 0 ? NP : 1;
   static_assert(!XH || (NP == 1 && !STEM), "bf16-storage tiles: single bf16 plane, not the stem");
   static_assert(!GL || (XH && BN >= 64), "direct-to-LDS tiles: bf16 storage, 64 or 128 columns");
-  static_assert(!BL || (NP == 0 && !STEM), "buffer-load tiles: exact-fp32, not the stem");
+  static_assert(!BL || (!XH && !STEM), "buffer-load tiles: fp32 tensors in memory (any arithmetic), not the stem");
   constexpr int BKT = XH ? 64 : BK;      // K extent of a tile
   constexpr int LDX = GL ? BKT : BKT + 8;  // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
   constexpr int EPL = XH ? 8 : 4;        // elements per thread, row and load
@@ -2572,7 +2572,9 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
   const bool gl = XH && g.wh && gl_on;
   // exact-fp32 tiles with whole 32-channel K tiles: buffer loads (HP_IGEMM_BL=0 keeps the flat loads: A/B runs)
   static const bool bl_on = !(getenv("HP_IGEMM_BL") && atoi(getenv("HP_IGEMM_BL")) == 0);
-  const bool bl = NP == 0 && !STEM && bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 * (g.mode == MODE_DECONV ? 8 : 1) < (1l << 31);
+  // (also the bf16 / split-bf16 modes on fp32 tensors: same loads, operands split on their way into LDS -- their flat
+  // loads sat behind per-row branches and were waited for one by one)
+  const bool bl = !XH && !g.xh && !g.wh && !STEM && bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 * (g.mode == MODE_DECONV ? 8 : 1) < (1l << 31);
   if (g.Nout > 64) {
     const unsigned tn = (unsigned)((g.Nout + 127) / 128);
     IgemmGeom gg = g;
@@ -2584,9 +2586,9 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
         return;
       }
     }
-    if constexpr (NP == 0 && !STEM) {
+    if constexpr (!XH && !STEM) {
       if (bl) {
-        hipLaunchKernelGGL((k_igemm<128, false, STATS, 0, false, false, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
+        hipLaunchKernelGGL((k_igemm<128, false, STATS, NP, false, false, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
         return;
       }
     }
@@ -2598,9 +2600,9 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
         return;
       }
     }
-    if constexpr (NP == 0 && !STEM) {
+    if constexpr (!XH && !STEM) {
       if (bl) {
-        hipLaunchKernelGGL((k_igemm<64, false, STATS, 0, false, false, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
+        hipLaunchKernelGGL((k_igemm<64, false, STATS, NP, false, false, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
         return;
       }
     }
