@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import _xformer as _xf
 
 
 class RotaryEmbedding(nn.Module):
@@ -150,11 +151,8 @@ class NlosPoseSformer(nn.Module):
                 _linear(att.view(rows, inner), a.to_out[0].weight, a.to_out[0].bias, prec, residual=x.view(rows, dim))
                 _lib.check(L.hp_layernorm_forward(x.data_ptr(), h.data_ptr(), rows, dim, ff.norm.weight.data_ptr(),
                                                   ff.norm.bias.data_ptr(), ff.norm.eps, 0, 0, st), "hp_layernorm_forward")
-                u = _linear(h.view(rows, dim), ff.fn.net[0].weight, ff.fn.net[0].bias, prec)
-                hid = ff.fn.net[3].weight.shape[1]
-                g = torch.empty(rows, hid, dtype=torch.float32, device=dev)
-                _lib.check(L.hp_geglu_forward(u.data_ptr(), g.data_ptr(), rows, hid, st), "hp_geglu_forward")
-                _linear(g, ff.fn.net[3].weight, ff.fn.net[3].bias, prec, residual=x.view(rows, dim))
+                # feed-forward: Linear -> GEGLU (in the GEMM's epilogue) -> Linear + residual
+                _xf.geglu_ff(x.view(rows, dim), h.view(rows, dim), ff.fn.net[0], ff.fn.net[3], prec)
             jt = torch.empty(b * nj, dim, dtype=torch.float32, device=dev)
             _lib.check(L.hp_layernorm_forward(x.data_ptr(), jt.data_ptr(), b * nj, dim, self.to_out[0].weight.data_ptr(),
                                               self.to_out[0].bias.data_ptr(), self.to_out[0].eps, nj, ntok, st), "hp_layernorm_forward")

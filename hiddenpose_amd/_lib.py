@@ -105,6 +105,7 @@ SIGNATURES = {
     "hp_bce_dice_finalize": (_i, [_vp, C.c_long, C.c_float, _fp, _vp]),
     "hp_bce_dice_backward_scaled": (_i, [_fp, _fp, _vp, _fp, _fp, C.c_long, C.c_float, C.c_float, _vp]),
     "hp_linear_forward": (_i, [_fp, _fp, _fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
+    "hp_linear_geglu_forward": (_i, [_fp, _fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_sformer_patchify": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "hp_layernorm_forward": (_i, [_fp, _fp, C.c_long, _i, _fp, _fp, C.c_float, _i, C.c_long, _vp]),
     "hp_geglu_forward": (_i, [_fp, _fp, C.c_long, _i, _vp]),

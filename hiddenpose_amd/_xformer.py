@@ -54,12 +54,38 @@ def attention(h2d, to_qkv, b, ntok, heads, dh, nj, n, frames, scale, sin_t=None,
     return att
 
 
+_PAIRED = {}   # id(Linear) -> (weight version, bias version, device, paired weight, paired bias)
+
+
+def _paired_rows(lin_in):
+    """The GEGLU input Linear's rows in the order hp_linear_geglu_forward wants: every 128 rows = 64 value rows followed by
+    their 64 gate rows.  Cached per module and recomputed when a parameter was written to (`_version`) or moved."""
+    w, b = lin_in.weight, lin_in.bias
+    key = id(lin_in)
+    ver = (w._version, None if b is None else b._version, w.device, w.data_ptr())
+    hit = _PAIRED.get(key)
+    if hit is None or hit[0] != ver:
+        hid = w.shape[0] // 2
+        idx = torch.arange(hid, device=w.device).view(-1, 64)
+        order = torch.cat((idx, idx + hid), dim=1).reshape(-1)
+        hit = (ver, w.detach().index_select(0, order).contiguous(), None if b is None else b.detach().index_select(0, order).contiguous())
+        _PAIRED[key] = hit
+    return hit[1], hit[2]
+
+
 def geglu_ff(x2d_resid, h2d, lin_in, lin_out, precision=0):
-    """x += W2 (u[:, :H] * gelu(u[:, H:])),  u = W1 h  (models/transformer.py:58-74)."""
-    u = linear(h2d, lin_in.weight, lin_in.bias, precision)
+    """x += W2 (u[:, :H] * gelu(u[:, H:])),  u = W1 h  (models/transformer.py:58-74).  With a hidden width that is a multiple
+    of 64 the GEGLU rides in the first GEMM's epilogue (u is never written); otherwise Linear, hp_geglu_forward, Linear."""
     hid = lin_out.weight.shape[1]
-    g = torch.empty(h2d.shape[0], hid, dtype=torch.float32, device=h2d.device)
-    _lib.check(_lib.lib().hp_geglu_forward(u.data_ptr(), g.data_ptr(), h2d.shape[0], hid, _st(h2d)), "hp_geglu_forward")
+    rows = h2d.shape[0]
+    g = torch.empty(rows, hid, dtype=torch.float32, device=h2d.device)
+    if hid % 64 == 0 and lin_in.weight.shape[0] == 2 * hid:
+        wp, bp = _paired_rows(lin_in)
+        _lib.check(_lib.lib().hp_linear_geglu_forward(h2d.data_ptr(), wp.data_ptr(), _lib.ptr(bp), g.data_ptr(), rows, h2d.shape[1],
+                                                      2 * hid, precision, _st(h2d)), "hp_linear_geglu_forward")
+    else:
+        u = linear(h2d, lin_in.weight, lin_in.bias, precision)
+        _lib.check(_lib.lib().hp_geglu_forward(u.data_ptr(), g.data_ptr(), rows, hid, _st(h2d)), "hp_geglu_forward")
     return linear(g, lin_out.weight, lin_out.bias, precision, residual=x2d_resid)
 
 

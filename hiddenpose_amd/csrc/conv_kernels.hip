@@ -57,6 +57,8 @@ struct IgemmGeom {
   int tn;                  // > 0: 1-D grid with the N tiles of one M tile adjacent on one XCD (set by the launcher)
   int xh, yh, ah;          // element type of the gathered tensor / written tensor / addend: 0 = fp32, 1 = bf16 (hp_ld4 / hp_st4)
   int wh;                  // packed weights are bf16 (bf16-storage tiles only)
+  int geglu;               // 1: GEGLU epilogue (hp_linear_geglu_forward): columns [0, 64) of every 128-column tile are values, [64, 128)
+                           //    their gates; Y has Nout / 2 columns and receives value * gelu(gate)
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     // m0 + trow, so the stores (and the addend / mask loads) are buffer accesses with a fixed per-thread offset and the row
     // group in the scalar offset -- no per-row index or 64-bit address arithmetic (exact-fp32 kernels pay every vector
     // instruction in matrix-pipe time; the K = 64 layers spent ~15 % of their time in this epilogue).
-    const bool fast = !IOH && dense_out && vec_ok && m0 + BM <= g.M && n0 + BN <= g.Nout;
+    const bool fast = !IOH && dense_out && vec_ok && m0 + BM <= g.M && n0 + BN <= g.Nout && !g.geglu;
     const long tile_el = m0 * g.Nout + n0;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)Y + tile_el), 0, 0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars =
@@ -675,6 +677,29 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         }
       }
       __syncthreads();
+      if constexpr (BN == 128) {
+        if (g.geglu && dense_out && m0 + BM <= g.M && n0 + BN <= g.Nout) {   // whole tile: value quads only, no bounds
+          constexpr int QH = Q / 2;   // 16 value quads per row, each paired with the quad 64 columns further
+          float* const yg = (float*)Y + m0 * (long)(g.Nout / 2) + n0 / 2;
+          float4 bv4 = make_float4(0, 0, 0, 0), bg4 = bv4;
+          const int qg = tid % QH, rg = tid / QH;
+          if (bias) {
+            bv4 = *(const float4*)(bias + n0 + 4 * qg);
+            bg4 = *(const float4*)(bias + n0 + BN / 2 + 4 * qg);
+          }
+          auto gl = [](float a, float t) { return a * 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); };
+#pragma unroll
+          for (int k2 = 0; k2 < (64 * QH) / CT; ++k2) {
+            const int row64 = rg + k2 * (CT / QH);
+            const int trow = (row64 >> 5) * (C::TM * 32) + h * 32 + (row64 & 31);
+            float4 v = *(const float4*)(smem + row64 * LDO + 4 * qg), gt = *(const float4*)(smem + row64 * LDO + BN / 2 + 4 * qg);
+            v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+            gt.x += bg4.x; gt.y += bg4.y; gt.z += bg4.z; gt.w += bg4.w;
+            *(float4*)(yg + (long)trow * (g.Nout / 2) + 4 * qg) = make_float4(gl(v.x, gt.x), gl(v.y, gt.y), gl(v.z, gt.z), gl(v.w, gt.w));
+          }
+          continue;
+        }
+      }
       if (fast) {
 #pragma unroll
         for (int k2 = 0; k2 < K2; ++k2) {
@@ -767,6 +792,20 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
         }
         float4 v = *(const float4*)(smem + row64 * LDO + 4 * q);
         const long yo = orow * g.Nout + n;
+        if constexpr (BN == 128) {   // every 128-column instantiation (hp_linear_geglu_forward launches no other; tensors are fp32)
+          if (g.geglu) {  // workgroup-uniform.  u = x W^T + b is never written: Y[m][n0 / 2 + c] = u[c] * gelu(u[64 + c])
+            if (q >= Q / 2) continue;
+            float4 gt = *(const float4*)(smem + row64 * LDO + 4 * q + BN / 2);
+            if (bias) {
+              const float4 bv = *(const float4*)(bias + n), bg = *(const float4*)(bias + n + BN / 2);
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+              gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
+            }
+            auto gl = [](float a, float t) { return a * 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); };  // k_geglu's expression
+            *(float4*)((float*)Y + orow * (g.Nout / 2) + (n0 / 2 + 4 * q)) = make_float4(gl(v.x, gt.x), gl(v.y, gt.y), gl(v.z, gt.z), gl(v.w, gt.w));
+            continue;
+          }
+        }
         if (vec_ok) {
           if (bias) {
             const float4 bv = *(const float4*)(bias + n);
@@ -2759,6 +2798,24 @@ extern "C" int hp_linear_forward(const float* x, const float* w, const float* bi
   {
     HP_PROF("linear_fwd", st);
     launch_igemm(p.fwd, 1, false, p.planes, x, w, bias, y, nullptr, addend, st);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_linear_geglu_forward(const float* x, const float* w_paired, const float* bias_paired, float* y, long M, int K,
+                                       int N2, int precision, void* stream) {
+  HP_REQUIRE(x && w_paired && y && M >= 1 && M < (1l << 31) && K >= 4, "hp_linear_geglu_forward: bad argument");
+  HP_REQUIRE(N2 >= 128 && N2 % 128 == 0, "hp_linear_geglu_forward: 2 * hidden must be a multiple of 128 (got %d)", N2);
+  hp_conv_desc d{1, 1, 1, (int)M, K, N2, 1, 1, 0, 0, precision, 0};
+  ConvPlan p;
+  int rc = make_plan(d, p);
+  if (rc) return rc;
+  p.fwd.geglu = 1;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    HP_PROF("linear_fwd", st);
+    launch_igemm(p.fwd, 1, false, p.planes, x, w_paired, bias_paired, y, nullptr, nullptr, st);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

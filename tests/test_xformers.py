@@ -100,3 +100,39 @@ def test_tokenpose_l_config_geometry_vs_oracle():
     ref = O.tokenpose_base(feat, m.state_dict(), patch_size=4, heads=8, num_keypoints=16, heatmap_size=[64, 64])
     y = m.cuda().eval()(feat.cuda())
     assert rel_l2(y, ref) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,dim,hid,prec", [(300, 64, 128, "fp32"), (1000, 256, 1024, "fp32"), (517, 96, 64, "bf16"), (384, 256, 1024, "bf16")])
+def test_geglu_in_the_gemm_epilogue_equals_the_three_launch_form(rows, dim, hid, prec):
+    """Feed-forward of the transformer heads (models/transformer.py:58-74, NlosPoseSformer.py:252-262): the first Linear with
+    its GEGLU in the GEMM's epilogue (hp_linear_geglu_forward on row-paired weights; u is never written) against Linear ->
+    hp_geglu_forward -> the same second Linear, and against float64.  Ragged row counts exercise the partial M tile."""
+    from hiddenpose_amd import _lib
+    from hiddenpose_amd import _xformer as X
+
+    g = torch.Generator().manual_seed(rows + hid)
+    lin_in, lin_out = torch.nn.Linear(dim, 2 * hid), torch.nn.Linear(hid, dim)
+    with torch.no_grad():
+        for p in (*lin_in.parameters(), *lin_out.parameters()):
+            p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() == 1 else p.shape[1] ** -0.5))
+    h = torch.randn(rows, dim, generator=g)
+    x0 = torch.randn(rows, dim, generator=g)
+    ud = torch.nn.functional.linear(h.double(), lin_in.weight.double(), lin_in.bias.double())
+    a, gate = ud.chunk(2, dim=-1)
+    ref = x0.double() + torch.nn.functional.linear(a * torch.nn.functional.gelu(gate), lin_out.weight.double(), lin_out.bias.double())
+    lin_in, lin_out, hc = lin_in.cuda(), lin_out.cuda(), h.cuda()
+    P = X.PREC[prec]
+    fused = X.geglu_ff(x0.cuda(), hc, lin_in, lin_out, P)
+    u = X.linear(hc, lin_in.weight, lin_in.bias, P)
+    gg = torch.empty(rows, hid, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().hp_geglu_forward(u.data_ptr(), gg.data_ptr(), rows, hid, X._st(hc)), "hp_geglu_forward")
+    plain = X.linear(gg, lin_out.weight, lin_out.bias, P, residual=x0.cuda())
+    assert rel_l2(fused, plain) < 1e-6
+    assert rel_l2(fused, ref) < (2e-6 if prec == "fp32" else 2e-2)
+    # the paired rows follow an in-place update of the parameter
+    with torch.no_grad():
+        lin_in.weight.mul_(0.5)
+        lin_in.bias.mul_(0.5)
+    fused2 = X.geglu_ff(x0.cuda(), hc, lin_in, lin_out, P)
+    assert rel_l2(fused2, fused) > 1e-3
