@@ -1825,6 +1825,10 @@ static bool use_f16_dconv() {
 static int run_dconv(const float* x, const float* w, const float* bias, const float* res, float* y, double* stats, float slope,
                      int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
                      int flip, int padmode, hipStream_t st, int precision = HP_PRECISION_FP32) {
+  // the kernels address a 4-channel group of planes through one buffer descriptor (31-bit byte offsets: beyond it loads read
+  // zero and stores are dropped)
+  HP_REQUIRE((long)Di * Hi * Wi * 16 < (1l << 31) && (long)Do * Ho * Wo * 16 < (1l << 31),
+             "thin-channel convolution: a volume of more than 2^27 voxels per channel is not supported (%d x %d x %d)", Di, Hi, Wi);
   const int tiles_x = (Wo + WG_TX - 1) / WG_TX, tiles_y = (Ho + WG_TY - 1) / WG_TY, cog_n = (cout + 3) / 4;
   const long cols = (long)tiles_x * tiles_y * B * cog_n;
   int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (1536 + cols - 1) / cols));
@@ -1962,6 +1966,8 @@ extern "C" int hp_dconv3_backward_data_p(const float* gy, const float* w, float*
     HP_PROF("dconv3_dgrad", st);
     return run_dconv(gy, w, nullptr, nullptr, gx, nullptr, 1.0f, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st, precision);
   }
+  HP_REQUIRE((long)D * H * W * 16 < (1l << 31),
+             "thin-channel data gradient: a volume of more than 2^27 voxels per channel is not supported (%d x %d x %d)", D, H, W);
   if (cin == 1 && cout == 1 && !use_mfma_c1()) {
     // single-channel layers (FeatureExtraction): the replicate fold inside the stencil kernel, one pass over (D, H, W)
     HP_PROF("dconv3_dgrad", st);
@@ -2035,6 +2041,8 @@ extern "C" int hp_dconv3_backward_weight_p(const float* x, const float* gy, floa
   HP_REQUIRE(x && gy && dw && workspace && B > 0, "hp_dconv3_backward_weight: bad argument");
   HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_dconv3_backward_weight_p: precision must be fp32 or bf16");
   hipStream_t st = (hipStream_t)stream;
+  HP_REQUIRE((long)D * H * W * 16 < (1l << 31),
+             "thin-channel weight gradient: a volume of more than 2^27 voxels per channel is not supported (%d x %d x %d)", D, H, W);
   const WgradGeom q = wgrad_geom(B, cin, cout, D, H, W);
   dim3 grid((unsigned)(q.tiles_x * q.tiles_y * q.zsplit), (unsigned)B, (unsigned)(q.cog_n * q.cig_n));
   float* partial = (float*)workspace;
