@@ -175,21 +175,28 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
     const float* p0 = ring + ((z - 1) & 3) * WG_PLANE + lbase;
     const float* p1 = ring + (z & 3) * WG_PLANE + lbase;
     const float* p2 = ring + ((z + 1) & 3) * WG_PLANE + lbase;
+    // 24 groups of 9 taps ((row, run) x dz), software-pipelined through two 9-register operand sets: the LDS reads of group
+    // g + 1 are in flight during the 9 MFMAs of group g.  (One (row, run) at a time -- 27 reads, then 27 MFMAs that wait for
+    // them -- exposed an LDS round trip eight times per plane: the matrix pipe was 42 % busy at two waves per SIMD.)
+    float ops[2][9];
+    auto ld9 = [&](int g_, float (&v)[9]) {
+      const int rq = g_ / 3, dz = g_ % 3;
+      const float* pl = (dz == 0 ? p0 : dz == 1 ? p1 : p2) + (rq >> 2) * WG_PX + (rq & 3) * 16;
 #pragma unroll
-    for (int rq = 0; rq < 8; ++rq) {
-      const int off = (rq >> 2) * WG_PX + (rq & 3) * 16;
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dz = 0; dz < 3; ++dz) {
-        const float* pl = (dz == 0 ? p0 : dz == 1 ? p1 : p2) + off;
+        for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = pl[dy * WG_PX + dx];
+    };
+    ld9(0, ops[0]);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+    for (int g_ = 0; g_ < 24; ++g_) {
+      if (g_ + 1 < 24) ld9(g_ + 1, ops[(g_ + 1) & 1]);
+      const int rq = g_ / 3, dz = g_ % 3;
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-            acc[(dz * 3 + dy) * 3 + dx] =
-                __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], pl[dy * WG_PX + dx], acc[(dz * 3 + dy) * 3 + dx], 0, 0, 0);
-      }
-      if (want_db) acc[27] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], 1.0f, acc[27], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);  // one (row, run) at a time: the unrolled body must not hoist all 216 LDS reads
+      for (int t9 = 0; t9 < 9; ++t9)
+        acc[dz * 9 + t9] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], ops[g_ & 1][t9], acc[dz * 9 + t9], 0, 0, 0);
+      if (dz == 2 && want_db) acc[27] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[rq], 1.0f, acc[27], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the groups in order (the scheduler would hoist all 216 LDS reads)
     }
   };
   // Everything a plane needs from global memory is requested one full step (g) or two steps (x planes) before it is
