@@ -744,7 +744,7 @@ struct EpiVals {
 // planes of a 4-channel chunk in the same 4-slot LDS ring as the weight gradient; the 27 weights of the current
 // input channel sit in registers (7 broadcast ds_read_b128 per channel and plane).  More than 4 input channels:
 // the chunks are separate z sweeps and every sweep after the first adds into y.
-template <int PADMODE, int S>
+template <int PADMODE, int S, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int cin,
                                                          int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad,
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
                                                          const float* __restrict__ res, double* __restrict__ stats, float slope) {
   __shared__ float ring[4 * WG_PLANE];
   __shared__ float sred[4][8];
-  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st1v = {0.f, 0.f, 0.f, 0.f}, st2v = {0.f, 0.f, 0.f, 0.f};   // per-channel sum / sum of squares of this lane's outputs
   __shared__ __attribute__((aligned(16))) float wl[4 * 4 * 28];  // [ci][co][28]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3;
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     // phase: one memory round trip hidden behind the MFMAs instead of eight exposed ones (a load per output row and channel,
     // each waited for on the spot), and the wait for it leaves the younger plane prefetches in flight.
     const bool last = c0 + 4 >= cin;
-    const bool need_a = c0 != 0, need_r = last && res != nullptr;   // sweep constants
+    const bool need_a = c0 != 0, need_r = !PLAIN && last && res != nullptr;   // sweep constants
     // `ok` of an output row / channel of a step and its scalar offset
     auto out_ok = [&](int z, bool valid, int r, int i) { return valid && y0 + 2 * wv + r < Ho && cog * 4 + i < cout; };
     auto out_off = [&](int z, int r, int i) { return (unsigned)(((long)i * ocs + ((long)z * Ho + (y0 + 2 * wv + r)) * Wo) * 4); };
@@ -882,24 +882,45 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
             ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, out_ok(z, true, r, i) ? xoff : 0x80000000u, out_ok(z, true, r, i) ? out_off(z, r, i) : 0u, 0));
       }
     };
+    // The epilogue is written on 4-channel VECTORS (packed fp32 adds / fmas: two instructions per four values) and carries
+    // only what the launch needs (PLAIN: no residual, no activation; statistics unmasked when the tile lies inside the row):
+    // next to fp32 MFMAs every vector-ALU instruction costs ~6 cycles of matrix-pipe time, and the scalar form -- add,
+    // residual select, leaky compare / multiply / two selects, row mask, square, accumulate, per element -- was 150 of them per
+    // step against 216 MFMAs (SQ_INSTS_VALU - SQ_INSTS_MFMA, round 3).
+    const f32x4 bv4 = {bv[0], bv[1], bv[2], bv[3]};
+    const bool xfull = x0 + WG_TX <= Wo;   // scalar
     auto epilogue_fast = [&](int z, const f32x4 (&acc)[2], const EpiVals& ev) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         if (y0 + 2 * wv + r < Ho) {   // loop-invariant
+          f32x4 v = acc[r];
+          if (need_a) v += (f32x4){ev.a[r][0], ev.a[r][1], ev.a[r][2], ev.a[r][3]};
+          else v += bv4;
+          if (last) {
+            if constexpr (!PLAIN) {
+              if (need_r) v += (f32x4){ev.r[r][0], ev.r[r][1], ev.r[r][2], ev.r[r][3]};
+              if (slope != 1.0f) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (cog * 4 + i < cout) {   // loop-invariant
-              float v = acc[r][i] + (need_a ? ev.a[r][i] : bv[i]);
-              if (last) {
-                if (need_r) v += ev.r[r][i];
-                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
-                const float vs = xin ? v : 0.f;
-                st1[i] += vs;
-                st2[i] += vs * vs;
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
               }
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, out_off(z, r, i), 0);
+            }
+            if (stats) {   // (channels past cout hold exact zeros: zero weights, zero bias)
+              if (xfull) {
+                st1v += v;
+                st2v += v * v;
+              } else {
+                const f32x4 vs = {xin ? v[0] : 0.f, xin ? v[1] : 0.f, xin ? v[2] : 0.f, xin ? v[3] : 0.f};
+                st1v += vs;
+                st2v += vs * vs;
+              }
             }
           }
+          // (`__builtin_bit_cast` applied directly to a vector ELEMENT yields element 0 on this compiler: go through a scalar)
+          const float vo[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (cog * 4 + i < cout)   // loop-invariant
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo[i]), yrs, xoff, out_off(z, r, i), 0);
         }
       }
     };
@@ -987,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     // per output channel of this group: all 64 lanes of the four waves hold partial sums
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float a = st1[i], q = st2[i];
+      float a = st1v[i], q = st2v[i];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         a += __shfl_xor(a, o);
@@ -1029,7 +1050,7 @@ __device__ __forceinline__ ds16x4 pack_bf16x4(float a, float b, float c, float d
   return __builtin_bit_cast(ds16x4, (dbf16x4){lo[0], lo[1], hi[0], hi[1]});
 }
 
-template <int PADMODE, int NQ, int S>
+template <int PADMODE, int NQ, int S, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int cin,
                                                          int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad,
@@ -1041,7 +1062,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
   __shared__ __attribute__((aligned(16))) ds16x4 ring[4 * SLOT];
   __shared__ __attribute__((aligned(16))) ds16x4 wl[NQ * 4 * 28];  // [quad][co][tap]
   __shared__ float sred[4][8];
-  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st1v = {0.f, 0.f, 0.f, 0.f}, st2v = {0.f, 0.f, 0.f, 0.f};   // per-channel sum / sum of squares of this lane's outputs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3;
   int t_ = blockIdx.x;
@@ -1156,7 +1177,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
     // phase: one memory round trip hidden behind the MFMAs instead of eight exposed ones (a load per output row and channel,
     // each waited for on the spot), and the wait for it leaves the younger plane prefetches in flight.
     const bool last = c0 + 4 * NQ >= cin;
-    const bool need_a = c0 != 0, need_r = last && res != nullptr;   // sweep constants
+    const bool need_a = c0 != 0, need_r = !PLAIN && last && res != nullptr;   // sweep constants
     // `ok` of an output row / channel of a step and its scalar offset
     auto out_ok = [&](int z, bool valid, int r, int i) { return valid && y0 + 2 * wv + r < Ho && cog * 4 + i < cout; };
     auto out_off = [&](int z, int r, int i) { return (unsigned)(((long)i * ocs + ((long)z * Ho + (y0 + 2 * wv + r)) * Wo) * 4); };
@@ -1180,24 +1201,45 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
             ev.r[r][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, out_ok(z, true, r, i) ? xoff : 0x80000000u, out_ok(z, true, r, i) ? out_off(z, r, i) : 0u, 0));
       }
     };
+    // The epilogue is written on 4-channel VECTORS (packed fp32 adds / fmas: two instructions per four values) and carries
+    // only what the launch needs (PLAIN: no residual, no activation; statistics unmasked when the tile lies inside the row):
+    // next to fp32 MFMAs every vector-ALU instruction costs ~6 cycles of matrix-pipe time, and the scalar form -- add,
+    // residual select, leaky compare / multiply / two selects, row mask, square, accumulate, per element -- was 150 of them per
+    // step against 216 MFMAs (SQ_INSTS_VALU - SQ_INSTS_MFMA, round 3).
+    const f32x4 bv4 = {bv[0], bv[1], bv[2], bv[3]};
+    const bool xfull = x0 + WG_TX <= Wo;   // scalar
     auto epilogue_fast = [&](int z, const f32x4 (&acc)[2], const EpiVals& ev) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         if (y0 + 2 * wv + r < Ho) {   // loop-invariant
+          f32x4 v = acc[r];
+          if (need_a) v += (f32x4){ev.a[r][0], ev.a[r][1], ev.a[r][2], ev.a[r][3]};
+          else v += bv4;
+          if (last) {
+            if constexpr (!PLAIN) {
+              if (need_r) v += (f32x4){ev.r[r][0], ev.r[r][1], ev.r[r][2], ev.r[r][3]};
+              if (slope != 1.0f) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (cog * 4 + i < cout) {   // loop-invariant
-              float v = acc[r][i] + (need_a ? ev.a[r][i] : bv[i]);
-              if (last) {
-                if (need_r) v += ev.r[r][i];
-                if (slope != 1.0f) v = v > 0.f ? v : v * slope;
-                const float vs = xin ? v : 0.f;
-                st1[i] += vs;
-                st2[i] += vs * vs;
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
               }
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, xoff, out_off(z, r, i), 0);
+            }
+            if (stats) {   // (channels past cout hold exact zeros: zero weights, zero bias)
+              if (xfull) {
+                st1v += v;
+                st2v += v * v;
+              } else {
+                const f32x4 vs = {xin ? v[0] : 0.f, xin ? v[1] : 0.f, xin ? v[2] : 0.f, xin ? v[3] : 0.f};
+                st1v += vs;
+                st2v += vs * vs;
+              }
             }
           }
+          // (`__builtin_bit_cast` applied directly to a vector ELEMENT yields element 0 on this compiler: go through a scalar)
+          const float vo[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (cog * 4 + i < cout)   // loop-invariant
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vo[i]), yrs, xoff, out_off(z, r, i), 0);
         }
       }
     };
@@ -1264,7 +1306,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
   if (stats) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float a = st1[i], q = st2[i];
+      float a = st1v[i], q = st2v[i];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         a += __shfl_xor(a, o);
@@ -1814,13 +1856,6 @@ static bool stencil_async() {  // A/B switch: HP_STENCIL_ASYNC=0 keeps the singl
   }();
   return v;
 }
-static int dconv_sets(int dflt) {  // A/B switch: planes in flight per workgroup + 1 (register sets of the z walk)
-  static const int v = [] {
-    const char* e = getenv("HP_DCONV_SETS");
-    return e ? atoi(e) : 0;
-  }();
-  return v >= 2 && v <= 4 ? v : dflt;
-}
 static bool use_f16_dconv() {
   static const bool v = [] {
     const char* e = getenv("HP_DCONV_16X16");
@@ -1859,18 +1894,17 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
     return HP_OK;
   }
   if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * cout, st));
+  const bool plain = !res && slope == 1.0f;   // no residual, no activation: the epilogue instantiation without either
   if (precision == HP_PRECISION_BF16) {
     // 8 input channels per sweep from 8 channels on (same LDS footprint as the exact kernel), 4 below
-#define HP_DBF_LAUNCH(PM, NQ, S)                                                                                            \
-  hipLaunchKernelGGL((k_dconv3_bf16<PM, NQ, S>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, \
+#define HP_DBF_LAUNCH(PM, NQ, PL)                                                                                           \
+  hipLaunchKernelGGL((k_dconv3_bf16<PM, NQ, 2, PL>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, \
                      wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope)
 #define HP_DBF_SETS(PM, NQ)                                          \
   do {                                                               \
-    if (sets == 2) HP_DBF_LAUNCH(PM, NQ, 2);                         \
-    else if (sets == 3) HP_DBF_LAUNCH(PM, NQ, 3);                    \
-    else HP_DBF_LAUNCH(PM, NQ, 4);                                   \
+    if (plain) HP_DBF_LAUNCH(PM, NQ, true);                          \
+    else HP_DBF_LAUNCH(PM, NQ, false);                               \
   } while (0)
-    const int sets = dconv_sets(2);
     if (cin > 4) {
       if (padmode) HP_DBF_SETS(1, 2); else HP_DBF_SETS(0, 2);
     } else {
@@ -1882,14 +1916,13 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
     return HP_OK;
   }
   if (!use_f16_dconv()) {
-#define HP_DMF_LAUNCH(PM, S)                                                                                                \
-  hipLaunchKernelGGL((k_dconv3_mfma<PM, S>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, \
+#define HP_DMF_LAUNCH(PM, PL)                                                                                               \
+  hipLaunchKernelGGL((k_dconv3_mfma<PM, 2, PL>), grid, dim3(256), 0, st, x, w, bias, y, cin, cout, Di, Hi, Wi, Do, Ho, Wo, pad, wsco, \
                      wsci, flip, tiles_x, tiles_y, zchunk, res, stats, slope)
-    const int sets = dconv_sets(2);
     if (padmode) {
-      if (sets == 2) HP_DMF_LAUNCH(1, 2); else if (sets == 3) HP_DMF_LAUNCH(1, 3); else HP_DMF_LAUNCH(1, 4);
+      if (plain) HP_DMF_LAUNCH(1, true); else HP_DMF_LAUNCH(1, false);
     } else {
-      if (sets == 2) HP_DMF_LAUNCH(0, 2); else if (sets == 3) HP_DMF_LAUNCH(0, 3); else HP_DMF_LAUNCH(0, 4);
+      if (plain) HP_DMF_LAUNCH(0, true); else HP_DMF_LAUNCH(0, false);
     }
 #undef HP_DMF_LAUNCH
     HP_CHECK_HIP(hipGetLastError());
