@@ -1898,7 +1898,11 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_full(const float* __restr
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  if (tid < 8) patch[SWG_PATCH + tid] = 0.f;  // the cell invalid taps read
+  if (tid < 8) patch[SWG_PATCH + tid] = 0.f;
+  const float* const ysrc = Ys + half * SWG_LDY + col;   // this lane's dZ fragment source: + voxel pair * 2 * SWG_LDY
+  const float* psrc[3];                                   // this lane's tap cell of the patch origin, per tap tile: + vbase(voxel pair)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) psrc[j] = patch + toff[j] + half;
 
   const long t0 = (long)blockIdx.x * tiles_per_wg, t1 = min(tiles_total, t0 + tiles_per_wg);
   // tile t+1 is fetched into registers while tile t is multiplied
@@ -1951,19 +1955,26 @@ __global__ __launch_bounds__(256, 2) void k_stem_wgrad_full(const float* __restr
     __syncthreads();
     if (t + 1 < t1) fetch(t + 1);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 4
-    for (int kk = 0; kk < SP_M / 2; ++kk) {
-      const int v = 2 * kk + half;  // voxel of this half-wave: (z, y, x) = (v >> 5, (v >> 3) & 3, v & 7)
-      const int vbase = (v >> 5) * SWG_PP + ((v >> 3) & 3) * SWG_PR + (v & 7);
-      float fa[2], fb[3];
-      fa[0] = Ys[v * SWG_LDY + col];
-      fa[1] = Ys[v * SWG_LDY + 32 + col];
+    // The K loop is fully unrolled with the lane part of every LDS address fixed for the whole kernel (ysrc, psrc[j]) and the
+    // voxel part a compile-time immediate of the ds_read: voxel v = 2 kk + half lies at vbase(2 kk) + half (2 kk is even, so
+    // the + 1 of the upper half-wave never carries out of the x field).  Computing the address per read -- add, select of
+    // the zero cell for taps >= 343, shift -- was 42 vector instructions per 24 MFMAs (SQ_INSTS_VALU: 2.5 per MFMA), each
+    // ~6 cycles of matrix-pipe time next to fp32 MFMAs.  Taps >= 343 now read tap 0's cell: their products are never stored.
 #pragma unroll
-      for (int j = 0; j < 3; ++j) fb[j] = patch[tval[j] ? vbase + toff[j] : SWG_PATCH];
+    for (int kk = 0; kk < SP_M / 2; ++kk) {
+      constexpr int ZZ = 0;  // (placeholder so that the lambdas below see constant expressions after unrolling)
+      const int ve = 2 * kk + ZZ;  // even voxel of the pair: (z, y, x) = (ve >> 5, (ve >> 3) & 3, ve & 7)
+      const int vbase = (ve >> 5) * SWG_PP + ((ve >> 3) & 3) * SWG_PR + (ve & 7);
+      float fa[2], fb[3];
+      fa[0] = ysrc[ve * SWG_LDY];
+      fa[1] = ysrc[ve * SWG_LDY + 32];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fb[j] = psrc[j][vbase];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // groups of 24 MFMAs: the scheduler must not hoist all 320 reads
     }
   }
 #pragma unroll
