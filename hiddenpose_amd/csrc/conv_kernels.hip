@@ -343,14 +343,27 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   // running (tap, channel tile) of the NEXT tile to gather: no division in the K loop
   int ld_tap = 0, ld_ci = 0;
   long ld_xoff = 0, ld_woff = 0;  // wave-uniform: tap displacement in X, tap slab in the packed weights
+  unsigned ninv_lo[4] = {0u, 0u, 0u, 0u}, ninv_hi[4] = {0u, 0u, 0u, 0u};   // BL: ~vmask, indexed by the tap itself
+  if constexpr (BL) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ninv_lo[i] = ~(unsigned)vmask[i];
+      ninv_hi[i] = ~(unsigned)(vmask[i] >> 32);
+    }
+  }
   auto tap_offsets = [&](int t) {
     int dz, dy, dx, widx;
     tap_info(g, cls, t, dz, dy, dx, widx);
     ld_xoff = (((long)dz * g.Hi + dy) * g.Wi + dx) * g.Cin;
     ld_woff = (long)widx * g.Nout * g.Cin;
     if constexpr (BL) {  // rows for which this tap falls outside the volume read zeros: an out-of-range offset
+      // bit t of the inverted mask lifted into bit 31 of the (< 2^31) row offset: v_bfe_u32 + v_lshl_or_b32 per row and tap
+      // (the 64-bit shift + test + select form was ~20 vector instructions per tap: with two K tiles per tap (64 channels)
+      // a tenth of the kernel's matrix-pipe time)
+      const unsigned tb = (unsigned)t & 31u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xvoff[i] = (vmask[i] & 1ull) ? xrow32[i] : OOB;
+      for (int i = 0; i < 4; ++i)
+        xvoff[i] = xrow32[i] | (__builtin_amdgcn_ubfe(t < 32 ? ninv_lo[i] : ninv_hi[i], tb, 1u) << 31);
     }
   };
   if (!STEM) tap_offsets(0);
@@ -415,8 +428,10 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
       }
       if (++ld_ci == kpt) {
         ld_ci = 0;
+        if constexpr (!BL) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vmask[i] >>= 1;
+          for (int i = 0; i < 4; ++i) vmask[i] >>= 1;
+        }
         if (++ld_tap < ntaps) tap_offsets(ld_tap);
       }
     }
