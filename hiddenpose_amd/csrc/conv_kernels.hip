@@ -436,6 +436,20 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
       }
     }
   };
+  // byte offsets of this thread's staging rows, made OPAQUE so that they stay in registers: the rows are 32 x 33 floats
+  // apart (4224 bytes, beyond the 8-bit dword offsets of ds_write2_b32), and left to itself the compiler re-derives every
+  // address with a v_add per K tile -- 14 vector instructions per tile, each ~6 cycles of matrix-pipe time
+  unsigned lds_a[4], lds_b[BN / 32];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lds_a[i] = (unsigned)(((r0 + 32 * i) * LDK + kq * 4) * 4);
+    asm volatile("" : "+v"(lds_a[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    lds_b[i] = (unsigned)((BM * LDK + (r0 + 32 * i) * LDK + kq * 4) * 4);   // from the arena's start: Bs = smem + BM * LDK
+    asm volatile("" : "+v"(lds_b[i]));
+  }
   auto store_tile = [&]() {
     if constexpr (XH) {
 #pragma unroll
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float* d = As + (r0 + 32 * i) * LDK + kq * 4;
+      float* d = (float*)((char*)As + lds_a[i]);
       d[0] = ra[i].x;
       d[1] = ra[i].y;
       d[2] = ra[i].z;
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     }
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
-      float* d = Bs + (r0 + 32 * i) * LDK + kq * 4;
+      float* d = (float*)((char*)smem + lds_b[i]);
       d[0] = rbw[i].x;
       d[1] = rbw[i].y;
       d[2] = rbw[i].z;
