@@ -54,23 +54,21 @@ def attention(h2d, to_qkv, b, ntok, heads, dh, nj, n, frames, scale, sin_t=None,
     return att
 
 
-_PAIRED = {}   # id(Linear) -> (weight version, bias version, device, paired weight, paired bias)
-
-
 def _paired_rows(lin_in):
     """The GEGLU input Linear's rows in the order hp_linear_geglu_forward wants: every 128 rows = 64 value rows followed by
-    their 64 gate rows.  Cached per module and recomputed when a parameter was written to (`_version`) or moved."""
+    their 64 gate rows.  Cached ON the module (an id()-keyed table would hand a new module the rows of a dead one whose id,
+    storage address and version counters it happens to reuse) and recomputed when a parameter was written to (`_version`),
+    replaced or moved."""
     w, b = lin_in.weight, lin_in.bias
-    key = id(lin_in)
-    ver = (w._version, None if b is None else b._version, w.device, w.data_ptr())
-    hit = _PAIRED.get(key)
-    if hit is None or hit[0] != ver:
+    ver = (id(w), w._version, w.data_ptr(), w.device, None if b is None else (id(b), b._version, b.data_ptr()))
+    hit = getattr(lin_in, "_hp_paired_rows", None)
+    if hit is None or hit[0] != ver or hit[1] is not w:
         hid = w.shape[0] // 2
         idx = torch.arange(hid, device=w.device).view(-1, 64)
         order = torch.cat((idx, idx + hid), dim=1).reshape(-1)
-        hit = (ver, w.detach().index_select(0, order).contiguous(), None if b is None else b.detach().index_select(0, order).contiguous())
-        _PAIRED[key] = hit
-    return hit[1], hit[2]
+        hit = (ver, w, w.detach().index_select(0, order).contiguous(), None if b is None else b.detach().index_select(0, order).contiguous())
+        object.__setattr__(lin_in, "_hp_paired_rows", hit)   # (plain attribute: not a buffer, not in the state_dict)
+    return hit[2], hit[3]
 
 
 def geglu_ff(x2d_resid, h2d, lin_in, lin_out, precision=0):
