@@ -78,6 +78,7 @@ SIGNATURES = {
     "hp_groupnorm_relu_backward_v2": (_i, [_fp, _fp, _fp, _i, _i, _i, C.c_long, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_maxpool3d_k2_forward": (_i, [_fp, _fp, C.c_long, _i, _i, _i, _vp]),
     "hp_maxpool3d_k2_backward": (_i, [_fp, _fp, _fp, C.c_long, _i, _i, _i, _vp]),
+    "hp_maxpool3d_k2_backward_add": (_i, [_fp, _fp, _fp, C.c_long, _fp, _i, _i, _i, _i, _i, _vp]),
     "hp_upsample_trilinear2x_forward": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "hp_upsample_trilinear2x_forward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "hp_upsample_trilinear2x_forward_ws": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

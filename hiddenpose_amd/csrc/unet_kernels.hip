@@ -235,8 +235,12 @@ __global__ __launch_bounds__(UT) void k_maxpool2_fwd(const float* __restrict__ x
 }
 
 // gradient goes to the FIRST maximum of each window (torch semantics)
+// `add` (optional): a second gradient of the pooled tensor's INPUT, summed in the same pass -- the U-Net's skip tensor feeds the
+// pool and the decoder's concatenation, and its two gradients used to meet in a separate accumulation pass.  `add` is read in
+// place from the concatenation's gradient: channel c of sample b lies at add + (b * add_bstride + c * D*H*W).
 __global__ __launch_bounds__(UT) void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ dy,
-                                                     float* __restrict__ dx, long planes, int D, int H, int W) {
+                                                     float* __restrict__ dx, long planes, int D, int H, int W,
+                                                     const float* __restrict__ add, long add_bstride, int C) {
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
   const long total = planes * Do * Ho * Wo;
   for (long i = (long)blockIdx.x * UT + threadIdx.x; i < total; i += (long)gridDim.x * UT) {
@@ -259,12 +263,23 @@ __global__ __launch_bounds__(UT) void k_maxpool2_bwd(const float* __restrict__ x
       }
     }
     const float g = dy[i];
+    const float* ap = nullptr;
+    if (add) {
+      const long bb = pl / C;
+      ap = add + bb * add_bstride + (pl - bb * C) * ((long)D * H * W) + (base - pl * ((long)D * H * W));
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int k0 = a * 4 + b * 2;
-        *(float2*)(dx + base + ((long)a * H + b) * W) = make_float2(arg == k0 ? g : 0.f, arg == k0 + 1 ? g : 0.f);
+        float2 o = make_float2(arg == k0 ? g : 0.f, arg == k0 + 1 ? g : 0.f);
+        if (add) {
+          const float2 e = *(const float2*)(ap + ((long)a * H + b) * W);
+          o.x += e.x;
+          o.y += e.y;
+        }
+        *(float2*)(dx + base + ((long)a * H + b) * W) = o;
       }
   }
 }
@@ -730,7 +745,22 @@ extern "C" int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* 
   hipStream_t st = (hipStream_t)stream;
   HP_PROF("maxpool2_bwd", st);
   hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ugrid(planes * (D / 2) * (H / 2) * (W / 2))), dim3(UT), 0, st, x, dy, dx, planes, D, H,
-                     W);
+                     W, (const float*)nullptr, 0l, 1);
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
+extern "C" int hp_maxpool3d_k2_backward_add(const float* x, const float* dy, const float* add, long add_batch_stride, float* dx, int B,
+                                            int C, int D, int H, int W, void* stream) {
+  HP_REQUIRE(x && dy && add && dx && B > 0 && C > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
+             "hp_maxpool3d_k2_backward_add: bad argument (even sizes required)");
+  HP_REQUIRE(add_batch_stride >= (long)C * D * H * W && (add_batch_stride & 1) == 0 && ((uintptr_t)add & 7) == 0,
+             "hp_maxpool3d_k2_backward_add: the addend's samples must not overlap and its rows must be 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  HP_PROF("maxpool2_bwd", st);
+  const long planes = (long)B * C;
+  hipLaunchKernelGGL(k_maxpool2_bwd, dim3(ugrid(planes * (D / 2) * (H / 2) * (W / 2))), dim3(UT), 0, st, x, dy, dx, planes, D, H,
+                     W, add, add_batch_stride, C);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }

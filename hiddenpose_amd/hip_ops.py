@@ -139,7 +139,7 @@ class _ConvGnRelu(torch.autograd.Function):
     the ReLU mask from z (the normalised tensor is not read back)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, groups, eps):
+    def forward(ctx, x, w, bias, gamma, beta, groups, eps, out=None):
         _need_cuda(x, "conv3_gn_relu")
         L = _lib.lib()
         x = x.contiguous()
@@ -148,7 +148,9 @@ class _ConvGnRelu(torch.autograd.Function):
         V = d * h * wd
         dev = x.device
         z = torch.empty(b, cout, d, h, wd, dtype=torch.float32, device=dev)
-        y = torch.empty_like(z)
+        # `out`: a contiguous (b, cout, d, h, wd) view to write y into (the U-Net hands the first half of a decoder's
+        # concatenation buffer here, so that the skip tensor never has to be copied into it)
+        y = out if out is not None and out.shape == z.shape and out.is_contiguous() and out.dtype == z.dtype else torch.empty_like(z)
         stats = torch.empty(2 * b * cout, dtype=torch.float64, device=dev)
         mean = torch.empty(b * groups, dtype=torch.float32, device=dev)
         rstd = torch.empty_like(mean)
@@ -186,7 +188,7 @@ class _ConvGnRelu(torch.autograd.Function):
                                                        aff[1].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                                                        _stream(z)), "hp_groupnorm_relu_backward_v2")
             gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0], ctx.prec)
-        return gx, dw, db, dgamma, dbeta, None, None
+        return gx, dw, db, dgamma, dbeta, None, None, None
 
 
 # ---------------------------------------------------------------- FeatureExtraction (rows A1, A2)
@@ -343,21 +345,66 @@ class _MaxPool2(torch.autograd.Function):
         return dx
 
 
+class _PoolSkip(torch.autograd.Function):
+    """(skip, pooled) = (x, max_pool3d(x, 2)) as ONE node: a U-Net level's output feeds the next level's pool AND the
+    decoder's concatenation (unet/unet3d.py:31-39, 42-62), and with one node for both the two gradients meet inside the
+    pool's backward kernel (hp_maxpool3d_k2_backward_add) -- the skip gradient is read in place from the concatenation's
+    gradient -- instead of being copied out and summed by a separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        b, c, d, h, w = x.shape
+        y = torch.empty(b, c, d // 2, h // 2, w // 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hp_maxpool3d_k2_forward(x.data_ptr(), y.data_ptr(), b * c, d, h, w, _stream(x)),
+                       "hp_maxpool3d_k2_forward")
+        ctx.save_for_backward(x)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_skip, g_pool):
+        (x,) = ctx.saved_tensors
+        if g_pool is None:
+            return g_skip
+        b, c, d, h, w = x.shape
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        V = d * h * w
+        with torch.cuda.device(x.device):
+            if g_skip is None:
+                _lib.check(L.hp_maxpool3d_k2_backward(x.data_ptr(), g_pool.contiguous().data_ptr(), dx.data_ptr(), b * c, d, h, w,
+                                                      _stream(x)), "hp_maxpool3d_k2_backward")
+            else:
+                st = g_skip.stride()
+                if not (st[4] == 1 and st[3] == w and st[2] == h * w and st[1] == V and st[0] >= c * V and st[0] % 2 == 0
+                        and g_skip.data_ptr() % 8 == 0):
+                    g_skip = g_skip.contiguous()
+                    st = g_skip.stride()
+                _lib.check(L.hp_maxpool3d_k2_backward_add(x.data_ptr(), g_pool.contiguous().data_ptr(), g_skip.data_ptr(), st[0],
+                                                          dx.data_ptr(), b, c, d, h, w, _stream(x)), "hp_maxpool3d_k2_backward_add")
+        return dx
+
+
 class _UpsampleCat(torch.autograd.Function):
     """cat([skip, upsample2x_trilinear_align_corners(x1)], dim=1) without materialising the upsampled tensor."""
 
     @staticmethod
-    def forward(ctx, x1, skip):
+    def forward(ctx, x1, skip, buf=None):
         L = _lib.lib()
         x1, skip = x1.contiguous(), skip.contiguous()
         b, c1, d, h, w = x1.shape
         c2 = skip.shape[1]
         assert skip.shape[2:] == (2 * d, 2 * h, 2 * w), "UNet3d skip and upsampled sizes must match (even input sizes)"
-        out = torch.empty(b, c1 + c2, 2 * d, 2 * h, 2 * w, dtype=torch.float32, device=x1.device)
+        # `buf`: the concatenation buffer whose first c2 channels ALREADY hold the skip tensor (it was produced there): no copy
+        in_place = (buf is not None and buf.shape == (b, c1 + c2, 2 * d, 2 * h, 2 * w) and buf.is_contiguous()
+                    and buf.dtype == torch.float32 and b == 1 and skip.data_ptr() == buf.data_ptr())
+        out = buf if in_place else torch.empty(b, c1 + c2, 2 * d, 2 * h, 2 * w, dtype=torch.float32, device=x1.device)
         st = _stream(x1)
         with torch.cuda.device(x1.device):
-            _lib.check(L.hp_channel_slice_copy(skip.data_ptr(), out.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 0, st),
-                       "hp_channel_slice_copy")
+            if not in_place:
+                _lib.check(L.hp_channel_slice_copy(skip.data_ptr(), out.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 0, st),
+                           "hp_channel_slice_copy")
             ws = torch.empty(int(L.hp_upsample_trilinear2x_forward_workspace_bytes(b, c1, d, h, w)) // 4, dtype=torch.float32,
                              device=x1.device)
             _lib.check(L.hp_upsample_trilinear2x_forward_ws(x1.data_ptr(), out.data_ptr(), b, c1, d, h, w, c1 + c2, c2,
@@ -371,16 +418,16 @@ class _UpsampleCat(torch.autograd.Function):
         b, c1, c2, d, h, w = ctx.dims
         dy = dy.contiguous()
         dx1 = torch.empty(b, c1, d, h, w, dtype=torch.float32, device=dy.device)
-        dskip = torch.empty(b, c2, 2 * d, 2 * h, 2 * w, dtype=torch.float32, device=dy.device)
+        # the skip's gradient = the first c2 channels of dy, handed on as a VIEW (no copy): its consumer is _PoolSkip's backward,
+        # which reads it in place; any other consumer takes a strided gradient like any other
+        dskip = dy[:, :c2]
         st = _stream(dy)
         with torch.cuda.device(dy.device):
-            _lib.check(L.hp_channel_slice_copy(dy.data_ptr(), dskip.data_ptr(), b, c2, 8 * d * h * w, c1 + c2, 0, 1, st),
-                       "hp_channel_slice_copy")
             ws = torch.empty(int(L.hp_upsample_trilinear2x_backward_workspace_bytes(b, c1, d, h, w)) // 4, dtype=torch.float32,
                              device=dy.device)
             _lib.check(L.hp_upsample_trilinear2x_backward_ws(dy.data_ptr(), dx1.data_ptr(), b, c1, d, h, w, c1 + c2, c2,
                                                              ws.data_ptr(), st), "hp_upsample_trilinear2x_backward_ws")
-        return dx1, dskip
+        return dx1, dskip, None
 
 
 class _Conv1x1(torch.autograd.Function):
@@ -468,16 +515,21 @@ def conv3d(x, w, b=None, stride=1, padding=0):
     return _Conv1x1.apply(x, w, b)
 
 
-def conv3_gn_relu(x, w, b, gw, gb, groups, eps):
-    return _ConvGnRelu.apply(x, w, b, gw, gb, groups, eps)
+def conv3_gn_relu(x, w, b, gw, gb, groups, eps, out=None):
+    return _ConvGnRelu.apply(x, w, b, gw, gb, groups, eps, out)
 
 
 def max_pool3d_2(x):
     return _MaxPool2.apply(x)
 
 
-def upsample_cat(x1, skip):
-    return _UpsampleCat.apply(x1, skip)
+def upsample_cat(x1, skip, buf=None):
+    return _UpsampleCat.apply(x1, skip, buf)
+
+
+def pool_and_skip(x):
+    """(x, max_pool3d(x, 2)) with the two gradients of x summed inside the pool's backward pass."""
+    return _PoolSkip.apply(x)
 
 
 # ---------------------------------------------------------------- posenet3d_50 (rows P1-P3)

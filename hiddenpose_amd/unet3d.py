@@ -11,6 +11,7 @@ objects only so that the state_dict keys match.
 """
 from __future__ import annotations
 
+import torch
 from torch import nn
 
 from . import _lib
@@ -29,10 +30,11 @@ class DoubleConv(nn.Module):
         assert num_groups == _GROUPS
         self.double_conv = nn.Sequential(*_conv_gn(in_channels, out_channels), *_conv_gn(out_channels, out_channels))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         for conv_idx in (0, 3):
             conv, gn = self.double_conv[conv_idx], self.double_conv[conv_idx + 1]
-            x = K.conv3_gn_relu(x, conv.weight, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps)
+            x = K.conv3_gn_relu(x, conv.weight, conv.bias, gn.weight, gn.bias, gn.num_groups, gn.eps,
+                                out if conv_idx == 3 else None)
         return x
 
 
@@ -56,8 +58,8 @@ class Up(nn.Module):
             raise NotImplementedError("NlosPose uses the trilinear variant only")
         self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, coarse, skip):
-        return self.conv(K.upsample_cat(coarse, skip))
+    def forward(self, coarse, skip, buf=None):
+        return self.conv(K.upsample_cat(coarse, skip, buf))
 
 
 class Out(nn.Module):
@@ -84,12 +86,28 @@ class UNet3d(nn.Module):
         self.out = Out(n_channels, in_channels)
 
     def _body(self, x):
-        skips = [self.conv(x)]
-        for name in ("enc1", "enc2", "enc3", "enc4"):
-            skips.append(getattr(self, name)(skips[-1]))
+        # Batch 1 (the 256 x 256 x 1024 run): a level's output is PRODUCED in the first half of its decoder's concatenation
+        # buffer (for one sample a channel slice of a planar tensor is contiguous), so the skip is never copied.  Every level
+        # concatenates as many upsampled channels as skip channels (_PLAN).
+        def cat_buffer(like, c, shape):
+            return torch.empty(1, 2 * c, *shape, dtype=like.dtype, device=like.device) if like.shape[0] == 1 else None
+
+        n = self.n_channels
+        bufs = [cat_buffer(x, n, x.shape[2:])]
+        skips = [self.conv(x, None if bufs[0] is None else bufs[0][:, :n])]
+        for li, name in enumerate(("enc1", "enc2", "enc3", "enc4")):
+            # a level's output feeds the next level's pool and the decoder's concatenation: one node for both, so that its two
+            # gradients are summed inside the pool's backward pass (hip_ops._PoolSkip)
+            skip, pooled = K.pool_and_skip(skips[-1])
+            skips[-1] = skip
+            cout = self._PLAN[li][3] * n
+            buf = cat_buffer(x, cout, pooled.shape[2:]) if name != "enc4" else None   # enc4's output is not a skip
+            bufs.append(buf)
+            skips.append(getattr(self, name).encoder[1](pooled, None if buf is None else buf[:, :cout]))
         y = skips.pop()
+        bufs.pop()
         for name in ("dec1", "dec2", "dec3", "dec4"):
-            y = getattr(self, name)(y, skips.pop())
+            y = getattr(self, name)(y, skips.pop(), bufs.pop())
         return y
 
     def forward(self, x):

@@ -295,6 +295,11 @@ int hp_groupnorm_relu_backward_v2(const float* dy, const float* z, float* dz, in
 /* MaxPool3d(2,2) (unet3d.py:35); planes = B*C */
 int hp_maxpool3d_k2_forward(const float* x, float* y, long planes, int D, int H, int W, void* stream);
 int hp_maxpool3d_k2_backward(const float* x, const float* dy, float* dx, long planes, int D, int H, int W, void* stream);
+/* the same with a second gradient of x summed in the same pass: the skip tensor of a U-Net level feeds the pool and the
+ * decoder's concatenation (unet3d.py:31-39, 42-62).  add: (B, >= C, D, H, W) read in place -- sample b, channel c at
+ * add + b * add_batch_stride + c * D*H*W (the first C channels of the concatenation's gradient) */
+int hp_maxpool3d_k2_backward_add(const float* x, const float* dy, const float* add, long add_batch_stride, float* dx, int B, int C,
+                                 int D, int H, int W, void* stream);
 /* nn.Upsample(scale_factor=2, mode='trilinear', align_corners=True) (unet3d.py:47), written into /
  * read from channel slice [c_off, c_off+C) of a (B, Ctot, 2D, 2H, 2W) tensor: the torch.cat of :61 */
 int hp_upsample_trilinear2x_forward(const float* x, float* y, int B, int C, int D, int H, int W, int Ctot, int c_off,

@@ -188,9 +188,9 @@ def test_unet_bf16_kernels_equal_exact_kernels_on_rounded_operands(dims, capsys)
     nodes = []
     orig = ops.conv3_gn_relu
 
-    def record(x, w, b, gw, gb, groups, eps):
+    def record(x, w, b, gw, gb, groups, eps, out=None):
         nodes.append((x.detach(), w.detach(), b.detach(), gw.detach(), gb.detach(), groups, eps))
-        return orig(x, w, b, gw, gb, groups, eps)
+        return orig(x, w, b, gw, gb, groups, eps, out)
 
     ops.conv3_gn_relu = record
     try:
@@ -227,3 +227,30 @@ def test_unet_bf16_kernels_equal_exact_kernels_on_rounded_operands(dims, capsys)
         print(f"\n[unet bf16] {dims}: 18 nodes, kernel vs rounded-operand emulation: y {worst[0]:.1e}, dx {worst[1]:.1e};  "
               f"whole U-Net, bf16 vs fp32 arithmetic: y {rel_l2(y_bf16, y_fp32):.2e}")
     assert 1e-4 < rel_l2(y_bf16, y_fp32) < 6e-2   # the mode really rounds; ~2.5e-3 per node, no blow-up
+
+
+@pytest.mark.parametrize("dims", [(2, 3, 4, 6, 8), (1, 4, 8, 8, 16)])
+def test_pool_and_skip_sums_both_gradients_in_the_pool_backward(dims):
+    """hip_ops.pool_and_skip: (x, max_pool3d(x, 2)) as one node -- the gradient of x is pool_backward(g_pool) + g_skip, the
+    skip gradient read in place from a larger (concatenation-shaped) gradient tensor; also with only one of the two used."""
+    B, C, D, H, W = dims
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, D, H, W, generator=g)
+    up = torch.randn(B, 2, D // 2, H // 2, W // 2, generator=g)          # a coarse tensor to concatenate behind the skip
+    wcat = torch.randn(B, C + 2, D, H, W, generator=g)                   # weights of the loss on the concatenation
+    wpool = torch.randn(B, C, D // 2, H // 2, W // 2, generator=g)
+    xd = x.double().requires_grad_(True)
+    cat = torch.cat([xd, F.interpolate(up.double(), scale_factor=2, mode="trilinear", align_corners=True)], dim=1)
+    ((cat * wcat.double()).sum() + (F.max_pool3d(xd, 2) * wpool.double()).sum()).backward()
+    xg = x.cuda().requires_grad_(True)
+    skip, pooled = ops.pool_and_skip(xg)
+    assert torch.equal(skip, xg.detach()) and rel_l2(pooled, F.max_pool3d(x.double(), 2)) == 0
+    (((ops.upsample_cat(up.cuda(), skip)) * wcat.cuda()).sum() + (pooled * wpool.cuda()).sum()).backward()
+    assert rel_l2(xg.grad, xd.grad) < 1e-6
+    for use in ("skip", "pool"):   # one-sided uses
+        xg2 = x.cuda().requires_grad_(True)
+        s2, p2 = ops.pool_and_skip(xg2)
+        ((s2 * wcat[:, :C].cuda()).sum() if use == "skip" else (p2 * wpool.cuda()).sum()).backward()
+        xd2 = x.double().requires_grad_(True)
+        ((xd2 * wcat[:, :C].double()).sum() if use == "skip" else (F.max_pool3d(xd2, 2) * wpool.double()).sum()).backward()
+        assert rel_l2(xg2.grad, xd2.grad) < 1e-6

@@ -23,8 +23,8 @@ for grad in (False, True):
 orig = ops.conv3_gn_relu
 trace = {}
 def rec(mode):
-    def f(x, w, b, gw, gb, groups, eps):
-        y = orig(x, w, b, gw, gb, groups, eps)
+    def f(x, w, b, gw, gb, groups, eps, out=None):
+        y = orig(x, w, b, gw, gb, groups, eps, out)
         trace.setdefault(mode, []).append((x.clone(), y.clone()))
         return y
     return f

@@ -8,7 +8,7 @@ B, T, N = 2, 32, 32
 un = UNet3d(1, 4); hpt.fill_module(un, "autoencoder."); un = un.cuda()
 u0 = (hpt.synthetic_meas(B, T, N, "uniform", seed=103) * 10.0).cuda()
 orig = ops.conv3_gn_relu
-def both(x, w, b, gw, gb, groups, eps):
+def both(x, w, b, gw, gb, groups, eps, out=None):
     out = {}
     for m in ("fp32", "bf16", "bf16emu"):
         p = ops.set_dconv_precision(m)
