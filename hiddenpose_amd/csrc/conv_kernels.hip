@@ -1675,14 +1675,15 @@ __global__ __launch_bounds__(CT) void k_wgrad_dense(const float* __restrict__ X,
 // cores, followed by a col2im fold of the tap columns into a 10x10x14 LDS patch that is
 // flushed to dX with one fp32 atomic per touched voxel.
 // LDS float atomics are ~100x slower than plain LDS traffic on gfx950, so the fold is a
-// gather: a chunk is (one kd) x (4 kh) x (7 kw, padded to 8) = 32 columns; each wave (one z slice
+// gather: a chunk is four (kd, kh) tap rows x (7 kw, padded to 8) = 32 columns; each wave (one z slice
 // of the patch) parks its 32x32 P tile in a staging array addressed by OUTPUT cell
-// [kh][jy][cx = jx + kw][kw], then every lane owns output cells and sums their <= 4 x 7 terms.
+// [row][jy][cx = jx + kw][kw], then every lane owns output cells and sums their <= 4 x 7 terms.
 constexpr int SP_Z = 4, SP_Y = 4, SP_X = 8, SP_M = SP_Z * SP_Y * SP_X;  // 128 voxels
 constexpr int SR_Z = SP_Z + 6, SR_Y = SP_Y + 6, SR_X = SP_X + 6, SR_N = SR_Z * SR_Y * SR_X;
 constexpr int SLD = 65;
 constexpr int SG_KW = 9;                                  // padded kw slots per cell
 constexpr int SG_N = 4 * SP_Y * SR_X * SG_KW;             // staging floats per wave
+constexpr int SD_CHUNKS = 13;                             // 49 (kd, kh) tap rows, four per chunk
 
 template <bool HB>
 __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
@@ -1698,7 +1699,7 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   __bf16* const Bh = (__bf16*)Bs;
   __shared__ float stage[4 * SG_N];
   __shared__ float patch[SR_N];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // A workgroup walks a run of patches along z in its (y, x) column.  The output patch is a ring of 10 planes: moving
   // on by one patch (4 planes) completes the 4 oldest planes -- only those are flushed to dX (fp32 atomics: the halo in
   // y and x is shared with the neighbouring columns) and become the 4 newest, zeroed; the other 6 carry over.  The dZ
@@ -1749,79 +1750,95 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   const int col = lane & 31, gi_l = col >> 3, kw_l = col & 7, half = lane >> 5;
   // staging write address of accumulator register r: lane part + compile-time register part
   const int sw_lane = ((gi_l * SP_Y) * SR_X + 4 * half + kw_l) * SG_KW + kw_l;
-  // weight chunk c+1 is fetched into registers while chunk c is multiplied and folded
+  // Tap columns: the 49 (kd, kh) rows of 7 kw taps are numbered flat = kd * 7 + kh and taken four at a time, each padded to 8
+  // columns -- 13 chunks of 32 columns (round 2: 14, one kd per chunk pair with a 3-row second half).  Wt is [flat][kw][64],
+  // so a chunk's weight tile is one contiguous run: weight chunk c+1 is fetched into registers while chunk c is multiplied and
+  // folded, as two 16-byte buffer loads per thread with a lane-fixed offset and the chunk as the scalar offset.  Column
+  // kw = 7 re-reads kw = 6 and rows past the 49th read as zero (descriptor bound): neither is ever parked or folded.
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, 343 * 64 * 4, 0x00020000);
+  unsigned wvoff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = tid + h * CT;  // 512 float4 = 32 columns x 16 quads
+    const int tr = i >> 4, q = i & 15;
+    wvoff[h] = (unsigned)((((tr >> 3) * 7 + min(tr & 7, 6)) * 64 + q * 4) * 4);
+  }
   float4 wv[2];
   auto fetch_w = [&](int chunk) {
-    const int kd = chunk >> 1, kh0 = (chunk & 1) * 4, npair = (chunk & 1) ? 3 : 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = tid + h * CT;  // 512 float4 = 32 columns x 16 quads
-      const int tr = i >> 4, q = i & 15;
-      const int gi = tr >> 3, kw = tr & 7;
-      wv[h] = (gi < npair && kw < 7) ? *(const float4*)(Wt + (long)(((kd * 7) + kh0 + gi) * 7 + kw) * 64 + q * 4)
-                                     : make_float4(0, 0, 0, 0);
-    }
+    for (int h = 0; h < 2; ++h)
+      wv[h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff[h], chunk * (4 * 7 * 64 * 4), 0));
   };
   // Fold bookkeeping, fixed per lane: lane < 56 owns the staging position (jy, cx) of this wave's slice and sums, for each
-  // of the chunk's kh rows gi, the 7 kw slots parked there: sum_kw P[(jy, cx - kw)][(gi, kw)] -- the part of output cell
-  // (row jy + gi, cx) that comes from voxel row jy.  Slots (cx, kw) with cx - kw outside the 8-voxel run are never written
+  // of the chunk's four rows gi, the 7 kw slots parked there: sum_kw P[(jy, cx - kw)][(gi, kw)] -- the part of output cell
+  // (row jy + kh, cx) that comes from voxel row jy.  Slots (cx, kw) with cx - kw outside the 8-voxel run are never written
   // by the park and stay zero from the start, so no term needs a validity test.  The four parts of a lane then go to four
-  // different patch rows, one kh row at a time (lanes of one step hit distinct cells; LDS operations of a wave are ordered).
-  const int f_jy = lane / SR_X, f_cx = lane - f_jy * SR_X;
+  // different patch rows, one row at a time (lanes of one step hit distinct cells; LDS operations of a wave are ordered);
+  // a part's cell is (plane, row) of its flat row -- scalar -- plus the lane number.
   const bool f_on = lane < SP_Y * SR_X;
-  const int fbase = f_on ? (f_jy * SR_X + f_cx) * SG_KW : 0;
+  const int fbase = f_on ? lane * SG_KW : 0;
   for (int i = tid; i < 4 * SG_N; i += CT) stage[i] = 0.f;
-  // Software pipeline over the 14 tap chunks: while the matrix cores run chunk c (a dependent chain of 32 MFMAs
+  // this wave's rows of the dZ tile stay in registers for all 13 chunks of a patch
+  float afr[HB ? 1 : 32];
+  bf16x8 ha[HB ? 4 : 1];
+  // Software pipeline over the 13 tap chunks: while the matrix cores run chunk c (a dependent chain of 32 MFMAs
   // on one accumulator tile), the same wave folds the P tile of chunk c-1 that it parked in its private staging
-  // array -- two LDS reads per MFMA slot -- so the fold costs no time of its own.  Workgroup barriers are needed
-  // only around the shared weight tile; the patch planes touched by the four waves within one step are distinct.
+  // array.  Next to fp32 MFMAs every other vector instruction of the SIMD costs matrix-pipe time, so the fold
+  // is kept short: 16 LDS reads (pairs), 16 adds (packed), 4 read-add-write steps with scalar cell addresses.  Workgroup
+  // barriers are needed only around the shared weight tile; the patch planes touched by the four waves within one step
+  // are distinct.
   auto step = [&](auto mm_c, auto fold_c, int chunk) {
     constexpr bool MM = decltype(mm_c)::value, FOLD = decltype(fold_c)::value;
     const int pc = chunk - 1;  // the chunk being folded
-    const int kdp = pc >> 1, kh0p = (pc & 1) * 4;
-    const int nkh_p = (pc & 1) ? 3 : 4;  // odd chunks hold 3 kh rows (the 4th staging row keeps the previous chunk's values)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float fpart[4] = {0.f, 0.f, 0.f, 0.f};
-    float fa = 0.f, fb = 0.f;
-    bf16x8 ha[HB ? 4 : 1], hb[HB ? 4 : 1];
+    f32x2 fp2[4][3];
+    float fp1[4], fpart[4];
+    float fb[2] = {0.f, 0.f}, nb[2] = {0.f, 0.f};   // weight operands, read a pair of K steps ahead (one ds_read2 per pair)
+    bf16x8 hb[HB ? 4 : 1];
     if constexpr (MM && HB) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        ha[ks] = *(const bf16x8*)(ahp + ks * 16);
-        hb[ks] = *(const bf16x8*)(bhp + ks * 16);
-      }
+      for (int ks = 0; ks < 4; ++ks) hb[ks] = *(const bf16x8*)(bhp + ks * 16);
     }
     if constexpr (MM && !HB) {
-      fa = ap[0];
-      fb = bp[0];
+      fb[0] = bp[0];
+      fb[1] = bp[2];
     }
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
-      float na = 0.f, nb = 0.f;
       if constexpr (MM && !HB) {
-        if (kk + 1 < 32) {
-          na = ap[2 * (kk + 1)];
-          nb = bp[2 * (kk + 1)];
+        if ((kk & 1) == 0 && kk + 2 < 32) {
+          nb[0] = bp[2 * (kk + 2)];
+          nb[1] = bp[2 * (kk + 3)];
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk], fb[kk & 1], acc, 0, 0, 0);
       }
       if constexpr (MM && HB) {  // the 4 K steps of the chunk, spread over the fold slots
         if ((kk & 7) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[kk >> 3], hb[kk >> 3], acc, 0, 0, 0);
       }
       if constexpr (FOLD) {
-        // slots 0 .. 27: term (gi, kw) = (kk / 7, kk % 7), one unconditional staging read and one add each;
-        // slots 28 .. 31: the part of kh row gi = kk - 28 goes to patch row kh0 + gi + jy of this wave's plane
-        if (kk < 28) {
-          const int gi = kk / 7, kw = kk % 7;  // compile-time after unrolling
-          fpart[gi] += sw[fbase + gi * (SP_Y * SR_X * SG_KW) + kw];
-        } else {
-          const int gi = kk - 28;
-          int slot = ring + wave + kdp;  // plane (wave + kdp) of the patch
-          slot = slot >= SR_Z ? slot - SR_Z : slot;
-          if (f_on && gi < nkh_p) patch[(slot * SR_Y + kh0p + gi + f_jy) * SR_X + f_cx] += fpart[gi];
-          // the next kh row's update of ANOTHER lane reads the cell this lane just wrote: keep the four read-add-write
+        // slots 0 .. 15: the 7 kw terms of row gi = kk / 4 as three pairs and a single (unconditional staging reads);
+        // slots 16 .. 19: their sum; slots 20 .. 23: the part of row gi goes to its patch row of this wave's plane
+        if (kk < 16) {
+          const int gi = kk >> 2, j = kk & 3;  // compile-time after unrolling
+          const float* src = sw + fbase + gi * (SP_Y * SR_X * SG_KW) + 2 * j;
+          if (j < 3) fp2[gi][j] = (f32x2){src[0], src[1]};
+          else fp1[gi] = src[0];
+        } else if (kk < 20) {
+          const int gi = kk - 16;
+          const f32x2 s2 = fp2[gi][0] + fp2[gi][1] + fp2[gi][2];
+          fpart[gi] = (s2[0] + s2[1]) + fp1[gi];
+        } else if (kk < 24) {
+          const int gi = kk - 20;
+          const int flat = 4 * pc + gi;  // scalar
+          if (flat < 49) {
+            const int kdp = flat / 7, khp = flat - 7 * kdp;
+            int slot = ring + wave + kdp;  // plane (wave + kd) of the patch
+            slot = slot >= SR_Z ? slot - SR_Z : slot;
+            if (f_on) patch[(slot * SR_Y + khp) * SR_X + lane] += fpart[gi];
+          }
+          // the next row's update of ANOTHER lane reads the cell this lane just wrote: keep the four read-add-write
           // steps in program order (per lane their addresses differ, so the compiler would otherwise be free to hoist
           // the later reads above this write)
           asm volatile("" ::: "memory");
@@ -1829,16 +1846,17 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
         }
       }
       if constexpr (MM && !HB) {
-        fa = na;
-        fb = nb;
+        if (kk & 1) {
+          fb[0] = nb[0];
+          fb[1] = nb[1];
+        }
       }
       // fp32: pin the fold slot to its MFMA; bf16: only 4 MFMAs per chunk -- the compiler is free to batch the fold's reads
       if constexpr (!HB) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (MM) {
       // park P: register r is voxel (jy = r>>2, jx = (r&3) + 4*half) of this wave's z slice
-      const int npair = (chunk & 1) ? 3 : 4;
-      if (kw_l < 7 && gi_l < npair) {
+      if (kw_l < 7 && 4 * chunk + gi_l < 49) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sw[sw_lane + ((r >> 2) * SR_X + (r & 3)) * SG_KW] = acc[r];
       }
@@ -1846,13 +1864,21 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   };
   for (int bz = bz_beg; bz < bz_end; ++bz) {
   const int z0 = bz * SP_Z;
-  __syncthreads();  // the previous patch's last fragment reads of the A tile are done
+  __syncthreads();  // the previous patch's last patch updates are done
   store_a();
   if (bz + 1 < bz_end) fetch_a(bz + 1);
   fetch_w(0);
-  for (int chunk = 0; chunk <= 14; ++chunk) {
+  __syncthreads();
+  if constexpr (HB) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ha[ks] = *(const bf16x8*)(ahp + ks * 16);
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) afr[kk] = ap[2 * kk];
+  }
+  for (int chunk = 0; chunk <= SD_CHUNKS; ++chunk) {
     __syncthreads();  // every wave is through the fragment reads of the previous weight tile and its patch update
-    if (chunk < 14) {
+    if (chunk < SD_CHUNKS) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int i = tid + h * CT;
@@ -1869,10 +1895,10 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
       }
     }
     __syncthreads();
-    if (chunk + 1 < 14) fetch_w(chunk + 1);
+    if (chunk + 1 < SD_CHUNKS) fetch_w(chunk + 1);
     __builtin_amdgcn_sched_barrier(0);
     if (chunk == 0) step(std::true_type{}, std::false_type{}, chunk);
-    else if (chunk < 14) step(std::true_type{}, std::true_type{}, chunk);
+    else if (chunk < SD_CHUNKS) step(std::true_type{}, std::true_type{}, chunk);
     else step(std::false_type{}, std::true_type{}, chunk);
   }
   __syncthreads();
