@@ -1689,13 +1689,11 @@ template <bool HB>
 __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
                                                    float* __restrict__ dX, int D, int H, int W, int pz, int py, int px,
                                                    int zchunk) {
-  // HB: the patch GEMM runs on the bf16 matrix cores (bf16 modes): both tiles are kept as bf16 rows of SHD = 72 elements
+  // HB: the patch GEMM runs on the bf16 matrix cores (bf16 modes): the weight tile is kept as bf16 rows of SHD = 72 elements
   // (144 bytes: the 16-byte fragment reads of 16 rows fall on 16 distinct 16-byte slots), operands rounded on their way in,
   // 4 v_mfma_f32_32x32x16_bf16 per chunk instead of 32 fp32 ones -- the fold, unchanged, then sets the pace.
   constexpr int SHD = 72;
-  __shared__ __attribute__((aligned(16))) float As[HB ? SP_M * SHD / 2 : SP_M * SLD];
   __shared__ __attribute__((aligned(16))) float Bs[HB ? 32 * SHD / 2 : 32 * SLD];
-  __bf16* const Ah = (__bf16*)As;
   __bf16* const Bh = (__bf16*)Bs;
   __shared__ float stage[4 * SG_N];
   __shared__ float patch[SR_N];
@@ -1713,39 +1711,24 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   const int b = blockIdx.y;
   const int y0 = by * SP_Y, x0 = bx * SP_X;
   for (int i = tid; i < SR_N; i += CT) patch[i] = 0.f;
-  float4 areg[SP_M / 16];
-  const int aq = tid & 15, ar0 = tid >> 4;
-  auto fetch_a = [&](int bz) {  // A tile: 128 voxels x 64 channels
+  // The dZ tile (128 voxels x 64 channels) never passes through LDS: the K order of the patch GEMM is free as long as both
+  // operands agree, so lane (voxel row = lane & 31 of this wave's z slice, half = lane >> 5) takes channels 32 * half ..
+  // 32 * half + 31 -- 128 contiguous bytes, eight 16-byte buffer loads with a lane-fixed offset -- and these ARE its 32
+  // (fp32) / 4 (bf16) A operands for all 13 chunks; the weight fragment of step kk is row 32 * half + kk of the weight tile.
+  // A voxel row outside the volume in y / x has its offset out of range, a z slice outside an empty descriptor: zeros.
+  const int a_ry = (lane & 31) >> 3, a_rx = lane & 7;
+  const unsigned avoff = (y0 + a_ry < H && x0 + a_rx < W) ? (unsigned)((((wave * H + a_ry) * W + a_rx) * 64 + 32 * (lane >> 5)) * 4) : 0x80000000u;
+  float4 areg[8];
+  auto fetch_a = [&](int bz) {
+    const float* base = dZ + ((((long)b * D + bz * SP_Z) * H + y0) * W + x0) * 64;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bz * SP_Z + wave < D ? 0x80000000u : 0u, 0x00020000);
 #pragma unroll
-    for (int pss = 0; pss < SP_M / 16; ++pss) {
-      const int r = ar0 + 16 * pss;
-      const int rz = r / (SP_Y * SP_X), ry = (r / SP_X) % SP_Y, rx = r % SP_X;
-      const int z = bz * SP_Z + rz, y = y0 + ry, x = x0 + rx;
-      areg[pss] = (z < D && y < H && x < W) ? *(const float4*)(dZ + ((((long)b * D + z) * H + y) * W + x) * 64 + aq * 4)
-                                           : make_float4(0, 0, 0, 0);
-    }
-  };
-  auto store_a = [&]() {
-#pragma unroll
-    for (int pss = 0; pss < SP_M / 16; ++pss) {
-      const int r = ar0 + 16 * pss;
-      if constexpr (HB) {
-        *(bf16x4*)(Ah + r * SHD + aq * 4) = to_bf16x4(areg[pss]);
-      } else {
-        float* d = As + r * SLD + aq * 4;
-        d[0] = areg[pss].x;
-        d[1] = areg[pss].y;
-        d[2] = areg[pss].z;
-        d[3] = areg[pss].w;
-      }
-    }
+    for (int j = 0; j < 8; ++j) areg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + 16u * j, 0, 0));
   };
   if (bz_beg < bz_end) fetch_a(bz_beg);
   int ring = 0;  // ring slot of the patch's first plane (z0 - 3)
-  const __bf16* const ahp = Ah + (wave * 32 + (lane & 31)) * SHD + 8 * (lane >> 5);
-  const __bf16* const bhp = Bh + (lane & 31) * SHD + 8 * (lane >> 5);
-  const float* ap = As + (wave * 32 + (lane & 31)) * SLD + (lane >> 5);
-  const float* bp = Bs + (lane & 31) * SLD + (lane >> 5);
+  const __bf16* const bhp = Bh + (lane & 31) * SHD + 32 * (lane >> 5);
+  const float* bp = Bs + (lane & 31) * SLD + 32 * (lane >> 5);
   float* sw = stage + wave * SG_N;
   const int col = lane & 31, gi_l = col >> 3, kw_l = col & 7, half = lane >> 5;
   // staging write address of accumulator register r: lane part + compile-time register part
@@ -1799,18 +1782,18 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
     bf16x8 hb[HB ? 4 : 1];
     if constexpr (MM && HB) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) hb[ks] = *(const bf16x8*)(bhp + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) hb[ks] = *(const bf16x8*)(bhp + ks * 8);
     }
     if constexpr (MM && !HB) {
       fb[0] = bp[0];
-      fb[1] = bp[2];
+      fb[1] = bp[1];
     }
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
       if constexpr (MM && !HB) {
         if ((kk & 1) == 0 && kk + 2 < 32) {
-          nb[0] = bp[2 * (kk + 2)];
-          nb[1] = bp[2 * (kk + 3)];
+          nb[0] = bp[kk + 2];
+          nb[1] = bp[kk + 3];
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[kk], fb[kk & 1], acc, 0, 0, 0);
       }
@@ -1864,18 +1847,23 @@ __global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ,
   };
   for (int bz = bz_beg; bz < bz_end; ++bz) {
   const int z0 = bz * SP_Z;
-  __syncthreads();  // the previous patch's last patch updates are done
-  store_a();
-  if (bz + 1 < bz_end) fetch_a(bz + 1);
-  fetch_w(0);
-  __syncthreads();
   if constexpr (HB) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ha[ks] = *(const bf16x8*)(ahp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x4 lo = to_bf16x4(areg[2 * ks]), hi = to_bf16x4(areg[2 * ks + 1]);
+      ha[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
   } else {
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) afr[kk] = ap[2 * kk];
+    for (int j = 0; j < 8; ++j) {
+      afr[4 * j] = areg[j].x;
+      afr[4 * j + 1] = areg[j].y;
+      afr[4 * j + 2] = areg[j].z;
+      afr[4 * j + 3] = areg[j].w;
+    }
   }
+  if (bz + 1 < bz_end) fetch_a(bz + 1);
+  fetch_w(0);
   for (int chunk = 0; chunk <= SD_CHUNKS; ++chunk) {
     __syncthreads();  // every wave is through the fragment reads of the previous weight tile and its patch update
     if (chunk < SD_CHUNKS) {
@@ -2911,15 +2899,22 @@ extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void*
   hipStream_t st = (hipStream_t)stream;
   if (p.stem) {
     HP_REQUIRE(d->Cout == 64, "stem data gradient: 64 output channels expected (got %d)", d->Cout);
+    HP_REQUIRE((long)d->Hi * d->Wi <= (1l << 21), "stem data gradient: H * W up to 2^21 (31-bit offsets inside a 4-plane dZ tile), got %d x %d", d->Hi, d->Wi);
     const size_t nb = sizeof(float) * (size_t)d->B * d->Di * d->Hi * d->Wi;
     if (addend) HP_CHECK_HIP(hipMemcpyAsync(dx, addend, nb, hipMemcpyDeviceToDevice, st));
     else HP_CHECK_HIP(hipMemsetAsync(dx, 0, nb, st));
     const int pz = (d->Di + SP_Z - 1) / SP_Z, py = (d->Hi + SP_Y - 1) / SP_Y, px = (d->Wi + SP_X - 1) / SP_X;
     HP_PROF("conv_stem_dgrad", st);
     // single-plane bf16 arithmetic: the patch GEMM on the bf16 matrix cores (fp32 in, fp32 out either way)
-    // ~1024 workgroups (2 resident per CU), each walking zchunk patches along z
+    // 3 workgroups resident per CU (768 slots), each walking zchunk patches along z: the z split that minimises
+    // (rounds of 768 workgroups) x (patches per workgroup + ~2 for the extra ring start / full flush of a split)
     const long cols = (long)py * px * d->B;
-    int zsplit = (int)std::max<long>(1, std::min<long>(pz, (1024 + cols - 1) / cols));
+    int zsplit = 1;
+    long best = -1;
+    for (int zs = 1; zs <= std::min(pz, 32); ++zs) {
+      const long cost = ((cols * zs + 767) / 768) * ((pz + zs - 1) / zs + 2);
+      if (best < 0 || cost < best) best = cost, zsplit = zs;
+    }
     if (const char* e = getenv("HP_STEM_DGRAD_ZSPLIT")) zsplit = std::max(1, std::min(pz, atoi(e)));  // tests: long runs on small volumes
     const int zchunk = (pz + zsplit - 1) / zsplit;
     zsplit = (pz + zchunk - 1) / zchunk;
