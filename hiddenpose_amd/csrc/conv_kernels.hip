@@ -1686,7 +1686,7 @@ constexpr int SG_N = 4 * SP_Y * SR_X * SG_KW;             // staging floats per 
 constexpr int SD_CHUNKS = 13;                             // 49 (kd, kh) tap rows, four per chunk
 
 template <bool HB>
-__global__ __launch_bounds__(CT) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
+__global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
                                                    float* __restrict__ dX, int D, int H, int W, int pz, int py, int px,
                                                    int zchunk) {
   // HB: the patch GEMM runs on the bf16 matrix cores (bf16 modes): the weight tile is kept as bf16 rows of SHD = 72 elements
