@@ -1683,7 +1683,7 @@ constexpr int SR_Z = SP_Z + 6, SR_Y = SP_Y + 6, SR_X = SP_X + 6, SR_N = SR_Z * S
 constexpr int SLD = 65;
 constexpr int SG_KW = 9;                                  // padded kw slots per cell
 constexpr int SG_N = 4 * SP_Y * SR_X * SG_KW;             // staging floats per wave
-constexpr int SD_CHUNKS = 13;                             // 49 (kd, kh) tap rows, four per chunk
+constexpr int SD_CHUNKS = 12;                             // 48 (kd, kh) tap rows, four per chunk; the 49th rides in the spare columns
 
 template <bool HB>
 __global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ dZ, const float* __restrict__ Wt,
@@ -1734,23 +1734,27 @@ __global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ 
   // staging write address of accumulator register r: lane part + compile-time register part
   const int sw_lane = ((gi_l * SP_Y) * SR_X + 4 * half + kw_l) * SG_KW + kw_l;
   // Tap columns: the 49 (kd, kh) rows of 7 kw taps are numbered flat = kd * 7 + kh and taken four at a time, each padded to 8
-  // columns -- 13 chunks of 32 columns (round 2: 14, one kd per chunk pair with a 3-row second half).  Wt is [flat][kw][64],
-  // so a chunk's weight tile is one contiguous run: weight chunk c+1 is fetched into registers while chunk c is multiplied and
-  // folded, as two 16-byte buffer loads per thread with a lane-fixed offset and the chunk as the scalar offset.  Column
-  // kw = 7 re-reads kw = 6 and rows past the 49th read as zero (descriptor bound): neither is ever parked or folded.
+  // columns -- 12 chunks of 32 columns hold rows 0 .. 47 (round 2: 14 chunks, one kd per chunk pair with a 3-row second half).
+  // The 49th row (kd = kh = 6) rides in the padding: column (row 0 of the chunk, slot 7) of chunk c < 7 carries its tap kw = c.
+  // Wt is [flat][kw][64], so a chunk's weight tile is one contiguous run: weight chunk c+1 is fetched into registers while
+  // chunk c is multiplied and folded, as two 16-byte buffer loads per thread with a lane-fixed offset and the chunk as the
+  // scalar offset (the 16 threads of the spare column step through row 48 instead).  The other slot-7 columns re-read kw = 6
+  // and the spare column of chunks 7 .. 11 reads past the end (zeros): neither is ever parked or folded.
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, 343 * 64 * 4, 0x00020000);
   unsigned wvoff[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int i = tid + h * CT;  // 512 float4 = 32 columns x 16 quads
     const int tr = i >> 4, q = i & 15;
-    wvoff[h] = (unsigned)((((tr >> 3) * 7 + min(tr & 7, 6)) * 64 + q * 4) * 4);
+    wvoff[h] = tr == 7 ? (unsigned)((48 * 7 * 64 + q * 4) * 4) : (unsigned)((((tr >> 3) * 7 + min(tr & 7, 6)) * 64 + q * 4) * 4);
   }
+  const int wvstep = (tid >> 4) == 7 ? (64 - 4 * 7 * 64) * 4 : 0;   // spare column: tap kw = chunk of row 48, against the scalar offset
   float4 wv[2];
   auto fetch_w = [&](int chunk) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      wv[h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff[h], chunk * (4 * 7 * 64 * 4), 0));
+      wv[h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, h == 0 ? (unsigned)((int)wvoff[0] + chunk * wvstep) : wvoff[1],
+                                                                                chunk * (4 * 7 * 64 * 4), 0));
   };
   // Fold bookkeeping, fixed per lane: lane < 56 owns the staging position (jy, cx) of this wave's slice and sums, for each
   // of the chunk's four rows gi, the 7 kw slots parked there: sum_kw P[(jy, cx - kw)][(gi, kw)] -- the part of output cell
@@ -1761,10 +1765,14 @@ __global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ 
   const bool f_on = lane < SP_Y * SR_X;
   const int fbase = f_on ? lane * SG_KW : 0;
   for (int i = tid; i < 4 * SG_N; i += CT) stage[i] = 0.f;
-  // this wave's rows of the dZ tile stay in registers for all 13 chunks of a patch
+  // The spare column's P values (row 48, tap kw = c in chunk c) are parked in the staging slots 7 and 8 that the regular
+  // columns leave free: chunk c writes plane (row c & 3, slot 7 + (c >> 2)) at cx = jx + c -- every (plane, cell) is written
+  // by one chunk only, so the cells it does not reach stay zero as well, and the last step of a patch sums the seven planes.
+  const bool p48 = col == 7;
+  // this wave's rows of the dZ tile stay in registers for all 12 chunks of a patch
   float afr[HB ? 1 : 32];
   bf16x8 ha[HB ? 4 : 1];
-  // Software pipeline over the 13 tap chunks: while the matrix cores run chunk c (a dependent chain of 32 MFMAs
+  // Software pipeline over the 12 tap chunks: while the matrix cores run chunk c (a dependent chain of 32 MFMAs
   // on one accumulator tile), the same wave folds the P tile of chunk c-1 that it parked in its private staging
   // array.  Next to fp32 MFMAs every other vector instruction of the SIMD costs matrix-pipe time, so the fold
   // is kept short: 16 LDS reads (pairs), 16 adds (packed), 4 read-add-write steps with scalar cell addresses.  Workgroup
@@ -1815,12 +1823,10 @@ __global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ 
         } else if (kk < 24) {
           const int gi = kk - 20;
           const int flat = 4 * pc + gi;  // scalar
-          if (flat < 49) {
-            const int kdp = flat / 7, khp = flat - 7 * kdp;
-            int slot = ring + wave + kdp;  // plane (wave + kd) of the patch
-            slot = slot >= SR_Z ? slot - SR_Z : slot;
-            if (f_on) patch[(slot * SR_Y + khp) * SR_X + lane] += fpart[gi];
-          }
+          const int kdp = flat / 7, khp = flat - 7 * kdp;
+          int slot = ring + wave + kdp;  // plane (wave + kd) of the patch
+          slot = slot >= SR_Z ? slot - SR_Z : slot;
+          if (f_on) patch[(slot * SR_Y + khp) * SR_X + lane] += fpart[gi];
           // the next row's update of ANOTHER lane reads the cell this lane just wrote: keep the four read-add-write
           // steps in program order (per lane their addresses differ, so the compiler would otherwise be free to hoist
           // the later reads above this write)
@@ -1839,10 +1845,21 @@ __global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ 
     }
     if constexpr (MM) {
       // park P: register r is voxel (jy = r>>2, jx = (r&3) + 4*half) of this wave's z slice
-      if (kw_l < 7 && 4 * chunk + gi_l < 49) {
+      const int s48 = (((chunk & 3) * SP_Y) * SR_X + chunk) * SG_KW + 7 + (chunk >> 2);  // scalar
+      const int swl = p48 ? s48 + 4 * half * SG_KW : sw_lane;
+      if (p48 ? chunk < 7 : kw_l < 7) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sw[sw_lane + ((r >> 2) * SR_X + (r & 3)) * SG_KW] = acc[r];
+        for (int r = 0; r < 16; ++r) sw[swl + ((r >> 2) * SR_X + (r & 3)) * SG_KW] = acc[r];
       }
+    }
+    if constexpr (FOLD && !MM) {
+      // last step of the patch: the 49th tap row -- output row 6 + jy of plane wave + 6
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) s += sw[fbase + ((c & 3) * SP_Y * SR_X) * SG_KW + 7 + (c >> 2)];
+      int slot = ring + wave + 6;
+      slot = slot >= SR_Z ? slot - SR_Z : slot;
+      if (f_on) patch[(slot * SR_Y + 6) * SR_X + lane] += s;
     }
   };
   for (int bz = bz_beg; bz < bz_end; ++bz) {
