@@ -33,7 +33,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 
 // four fp32 -> four bf16 (round to nearest even; two v_cvt_pk_bf16_f32)
@@ -196,8 +195,8 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
 // returns 0.  Why it matters: tools/micro/mfma_coexec.hip -- while one wave streams fp32 MFMAs, vector-ALU, vector-memory
 // and LDS-read instructions of the OTHER waves of that SIMD do not issue at all, i.e. every such instruction of the K loop
 // is paid in matrix-pipe time whichever wave executes it.
-template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false, bool AD = false>
-__global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false>
+__global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, void* __restrict__ Y,
                                               double* __restrict__ stats, const void* __restrict__ addend,
                                               const unsigned char* __restrict__ amask, IgemmGeom g) {
@@ -232,7 +231,6 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
   static_assert(!XH || (NP == 1 && !STEM), "bf16-storage tiles: single bf16 plane, not the stem");
   static_assert(!GL || (XH && BN >= 64), "direct-to-LDS tiles: bf16 storage, 64 or 128 columns");
   static_assert(!BL || (!XH && !STEM), "buffer-load tiles: fp32 tensors in memory (any arithmetic), not the stem");
-  static_assert(!AD || (BL && NP == 0 && BN == 64), "A operands straight from memory: exact-fp32 buffer-load kernel, 64 columns");
   constexpr int BKT = XH ? 64 : BK;      // K extent of a tile
   constexpr int LDX = GL ? BKT : BKT + 8;  // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
   constexpr int EPL = XH ? 8 : 4;        // elements per thread, row and load
@@ -267,22 +265,14 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
 
   // ---- per-thread gather rows: r0 + 32 i
-  // AD: the A tile never passes through LDS.  The K order inside a 32-channel tile is free as long as both operands agree,
-  // so lane (row = lane & 31, half = lane >> 5) of the wave that multiplies tile rows wm * 64 + 32 i + row takes channels
-  // 16 * half .. 16 * half + 15 of those rows -- four 16-byte buffer loads per row, which ARE its 16 A operands of the K
-  // tile -- and the B tile is staged with channel 16 h + j at position 2 j + h, where the usual fragment read of step j
-  // finds it.  Per K tile and wave that removes 8 of 12 ds_write2_b32 (17-30 cycles of matrix-pipe time each next to fp32
-  // MFMAs: tools/micro/mfma_lds_width.hip) and 32 of 48 fragment reads; the two waves that share rows load them twice
-  // (second time from L1 / L2).
-  constexpr int NR = AD ? TileCfg<BN>::TM : 4;   // gathered rows per thread
   const int kq0 = tid & 7, r0 = tid >> 3;
   // GL: this thread's LDS chunk kq0 of rows r0 + 32 i is filled from memory chunk kq0 ^ swizzle(row) (same for every i)
   const int kq = GL ? (kq0 ^ ((r0 >> 1) & 7)) : kq0;
   int rb[4], rz[4], ry[4], rx[4];
   bool rv[4];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const long m = m0 + (AD ? wm * (C::TM * 32) + (lane & 31) : r0) + 32 * i;
+  for (int i = 0; i < 4; ++i) {
+    const long m = m0 + r0 + 32 * i;
     rv[i] = m < g.M;
     grid_coords(g, rv[i] ? m : 0, rb[i], rz[i], ry[i], rx[i]);
     rx[i] *= g.s;
@@ -300,8 +290,8 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
   unsigned long long vmask[4];
   bool wvalid[BN / 32];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    rowoff[i] = ((((long)rb[i] * g.Di + rz[i]) * g.Hi + ry[i]) * g.Wi + rx[i]) * g.Cin + (AD ? 16 * (lane >> 5) : kq * EPL);
+  for (int i = 0; i < 4; ++i) {
+    rowoff[i] = ((((long)rb[i] * g.Di + rz[i]) * g.Hi + ry[i]) * g.Wi + rx[i]) * g.Cin + kq * EPL;
     vmask[i] = 0ull;
   }
   if constexpr (!STEM) {
@@ -309,7 +299,7 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
       int dz, dy, dx, widx;
       tap_info(g, cls, t, dz, dy, dx, widx);
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
+      for (int i = 0; i < 4; ++i) {
         const bool ok = rv[i] && (unsigned)(rz[i] + dz) < (unsigned)g.Di && (unsigned)(ry[i] + dy) < (unsigned)g.Hi &&
                         (unsigned)(rx[i] + dx) < (unsigned)g.Wi;
         vmask[i] = (vmask[i] << 1) | (ok ? 1ull : 0ull);
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
     grid_coords(g, m0 < g.M ? m0 : 0, b0, z0, y0, x0);
     rowbase = ((((long)b0 * g.Di + z0 * g.s) * g.Hi + y0 * g.s) * g.Wi + x0 * g.s) * g.Cin;
 #pragma unroll
-    for (int i = 0; i < NR; ++i) xrow32[i] = rv[i] ? (unsigned)((rowoff[i] - rowbase) * 4) : OOB;
+    for (int i = 0; i < 4; ++i) xrow32[i] = rv[i] ? (unsigned)((rowoff[i] - rowbase) * 4) : OOB;
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) wvoff[i] = wvalid[i] ? (unsigned)(wrow[i] * 4) : OOB;
   }
@@ -356,7 +346,7 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
   unsigned ninv_lo[4] = {0u, 0u, 0u, 0u}, ninv_hi[4] = {0u, 0u, 0u, 0u};   // BL: ~vmask, indexed by the tap itself
   if constexpr (BL) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
+    for (int i = 0; i < 4; ++i) {
       ninv_lo[i] = ~(unsigned)vmask[i];
       ninv_hi[i] = ~(unsigned)(vmask[i] >> 32);
     }
@@ -372,12 +362,12 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
       // a tenth of the kernel's matrix-pipe time)
       const unsigned tb = (unsigned)t & 31u;
 #pragma unroll
-      for (int i = 0; i < NR; ++i)
+      for (int i = 0; i < 4; ++i)
         xvoff[i] = xrow32[i] | (__builtin_amdgcn_ubfe(t < 32 ? ninv_lo[i] : ninv_hi[i], tb, 1u) << 31);
     }
   };
   if (!STEM) tap_offsets(0);
-  auto load_tile = [&](int kt, f32x4* adst = nullptr) {
+  auto load_tile = [&](int kt) {
     if constexpr (STEM) {
       // single input channel, 7^3 taps spread along K: element (row, kk) = x[voxel + off(kk)]
       const int kbase = kt * BK + kq * 4;
@@ -424,16 +414,8 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
         }
       } else if constexpr (BL) {
         const unsigned xs = (unsigned)((ld_xoff - min_xoff + cofs) * 4), ws = (unsigned)((ld_woff + cofs) * 4);
-        if constexpr (AD) {
 #pragma unroll
-          for (int i = 0; i < NR; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              adst[i * 4 + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i] + 16u * q, xs, 0));
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i], xs, 0));
-        }
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i], xs, 0));
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) rbw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff[i], ws, 0));
       } else {
@@ -461,11 +443,11 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     lds_a[i] = (unsigned)(((r0 + 32 * i) * LDK + kq * 4) * 4);
-    if constexpr (!AD) asm volatile("" : "+v"(lds_a[i]));
+    asm volatile("" : "+v"(lds_a[i]));
   }
 #pragma unroll
   for (int i = 0; i < BN / 32; ++i) {
-    lds_b[i] = (unsigned)((BM * LDK + (r0 + 32 * i) * LDK + (AD ? (kq & 3) * 8 + (kq >> 2) : kq * 4)) * 4);   // from the arena's start: Bs = smem + BM * LDK
+    lds_b[i] = (unsigned)((BM * LDK + (r0 + 32 * i) * LDK + kq * 4) * 4);   // from the arena's start: Bs = smem + BM * LDK
     asm volatile("" : "+v"(lds_b[i]));
   }
   auto store_tile = [&]() {
@@ -502,24 +484,21 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
       }
       return;
     }
-    if constexpr (!AD) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float* d = (float*)((char*)As + lds_a[i]);
-        d[0] = ra[i].x;
-        d[1] = ra[i].y;
-        d[2] = ra[i].z;
-        d[3] = ra[i].w;
-      }
+    for (int i = 0; i < 4; ++i) {
+      float* d = (float*)((char*)As + lds_a[i]);
+      d[0] = ra[i].x;
+      d[1] = ra[i].y;
+      d[2] = ra[i].z;
+      d[3] = ra[i].w;
     }
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) {
       float* d = (float*)((char*)smem + lds_b[i]);
-      constexpr int SK = AD ? 2 : 1;   // AD: channel 16 h + j of the K tile sits at position 2 j + h
       d[0] = rbw[i].x;
-      d[SK] = rbw[i].y;
-      d[2 * SK] = rbw[i].z;
-      d[3 * SK] = rbw[i].w;
+      d[1] = rbw[i].y;
+      d[2] = rbw[i].z;
+      d[3] = rbw[i].w;
     }
   };
 
@@ -612,45 +591,7 @@ __global__ __launch_bounds__(CT, ((NP == 0 && BN == 128) || AD) ? 3 : 1) void k_
   const __bf16* ahp = Ah + (wm * C::TM * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   const __bf16* bhp = Bh + (wn * C::TN * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   // kt = -1 is the prologue: one call site for the gather keeps the pipeline uniform
-  if constexpr (AD) {
-    // two register sets for the A operands, alternating by K tile (the loop is unrolled by two so that both are named)
-    f32x4 aq[2][C::TM * 4];
-    load_tile(0, aq[0]);
-    store_tile();
-    __syncthreads();
-    auto body = [&](auto par, int kt) {
-      constexpr int P = decltype(par)::value;
-      if (kt + 1 < KT) load_tile(kt + 1, aq[P ^ 1]);
-      float fb[2][C::TN];
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) fb[0][j] = bp[j * 32 * LDK];
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < BK / 2) {
-#pragma unroll
-          for (int j = 0; j < C::TN; ++j) fb[nxt][j] = bp[j * 32 * LDK + 2 * (kk + 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-          for (int j = 0; j < C::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[P][i * 4 + (kk >> 2)][kk & 3], fb[cur][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-      if (kt + 1 < KT) {
-        store_tile();
-        __syncthreads();
-      }
-    };
-    for (int kt = 0; kt < KT; kt += 2) {
-      body(std::integral_constant<int, 0>{}, kt);
-      if (kt + 1 < KT) body(std::integral_constant<int, 1>{}, kt + 1);
-    }
-  }
-  for (int kt = -1; kt < ((GL || AD) ? -1 : KT); ++kt) {
+  for (int kt = -1; kt < (GL ? -1 : KT); ++kt) {
     if (kt + 1 < KT) load_tile(kt + 1);
     if (BF && kt >= 0) {
       // v_mfma_f32_32x32x16_bf16: lane (row = lane&31, half = lane>>5) feeds k = 8*half .. 8*half+7
@@ -2771,14 +2712,6 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
     }
     if constexpr (!XH && !STEM) {
       if (bl) {
-        // exact fp32: A operands straight from memory (HP_IGEMM_AD=0 keeps the LDS-staged A tile: A/B runs)
-        static const bool ad_on = !(getenv("HP_IGEMM_AD") && atoi(getenv("HP_IGEMM_AD")) == 0);
-        if constexpr (NP == 0) {
-          if (ad_on) {
-            hipLaunchKernelGGL((k_igemm<64, false, STATS, 0, false, false, true, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
-            return;
-          }
-        }
         hipLaunchKernelGGL((k_igemm<64, false, STATS, NP, false, false, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
         return;
       }
