@@ -33,7 +33,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 
 // four fp32 -> four bf16 (round to nearest even; two v_cvt_pk_bf16_f32)
@@ -196,8 +195,8 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
 // returns 0.  Why it matters: tools/micro/mfma_coexec.hip -- while one wave streams fp32 MFMAs, vector-ALU, vector-memory
 // and LDS-read instructions of the OTHER waves of that SIMD do not issue at all, i.e. every such instruction of the K loop
 // is paid in matrix-pipe time whichever wave executes it.
-template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false, bool GF = false>
-__global__ __launch_bounds__(CT, GF ? 2 : (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false>
+__global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, void* __restrict__ Y,
                                               double* __restrict__ stats, const void* __restrict__ addend,
                                               const unsigned char* __restrict__ amask, IgemmGeom g) {
@@ -232,15 +231,13 @@ __global__ __launch_bounds__(CT, GF ? 2 : (NP == 0 && BN == 128) ? 3 : 1) void k
   static_assert(!XH || (NP == 1 && !STEM), "bf16-storage tiles: single bf16 plane, not the stem");
   static_assert(!GL || (XH && BN >= 64), "direct-to-LDS tiles: bf16 storage, 64 or 128 columns");
   static_assert(!BL || (!XH && !STEM), "buffer-load tiles: fp32 tensors in memory (any arithmetic), not the stem");
-  static_assert(!GF || (NP == 0 && !XH && !STEM && !GL && !BL && BN >= 64), "fp32 direct-to-LDS tiles: exact fp32, 64 or 128 columns");
-  constexpr bool GLX = GL || GF;   // tiles go from memory straight into LDS: two buffers of unpadded, swizzled 128-byte rows
   constexpr int BKT = XH ? 64 : BK;      // K extent of a tile
   constexpr int LDX = GL ? BKT : BKT + 8;  // XH: bf16 tile row (144 bytes: 16-byte fragment reads of 16 rows hit 16 distinct slots)
   constexpr int EPL = XH ? 8 : 4;        // elements per thread, row and load
   constexpr int ARENA0 = (BM + BN) * LDK > NP * (BM + BN) * LDH / 2 ? (BM + BN) * LDK : NP * (BM + BN) * LDH / 2;
   constexpr int ARENA1 = XH && (BM + BN) * LDX / 2 > ARENA0 ? (BM + BN) * LDX / 2 : ARENA0;
   constexpr int GLBUF = (BM + BN) * 64;  // bf16 elements per buffer (GL)
-  constexpr int ARENA = GLX ? GLBUF : ARENA1;  // GL: two buffers of (BM + BN) x 64 bf16 = (BM + BN) * 64 floats
+  constexpr int ARENA = GL ? GLBUF : ARENA1;  // GL: two buffers of (BM + BN) x 64 bf16 = (BM + BN) * 64 floats
   __shared__ __attribute__((aligned(16))) float smem[ARENA];
   float* const As = smem;
   float* const Bs = smem + BM * LDK;
@@ -270,7 +267,7 @@ __global__ __launch_bounds__(CT, GF ? 2 : (NP == 0 && BN == 128) ? 3 : 1) void k
   // ---- per-thread gather rows: r0 + 32 i
   const int kq0 = tid & 7, r0 = tid >> 3;
   // GL: this thread's LDS chunk kq0 of rows r0 + 32 i is filled from memory chunk kq0 ^ swizzle(row) (same for every i)
-  const int kq = GLX ? (kq0 ^ ((r0 >> 1) & 7)) : kq0;
+  const int kq = GL ? (kq0 ^ ((r0 >> 1) & 7)) : kq0;
   int rb[4], rz[4], ry[4], rx[4];
   bool rv[4];
 #pragma unroll
@@ -588,98 +585,13 @@ __global__ __launch_bounds__(CT, GF ? 2 : (NP == 0 && BN == 128) ? 3 : 1) void k
     }
   }
 
-  if constexpr (GF) {
-    // Exact fp32 with the tiles loaded straight into LDS (same byte geometry as the bf16 GL tiles: a 32-channel fp32 row is
-    // 128 bytes): no staging registers, no ds_write pass -- ds_write2_b32 costs 17-30 cycles of matrix-pipe time next to
-    // fp32 MFMAs (tools/micro/mfma_lds_width.hip) and the register-staged kernel issues 16 per K tile -- and one barrier per
-    // K tile.  Fragments are 16-byte reads: the K order inside a tile is free as long as both operands agree, so lane
-    // (row, half) takes chunk 2 ks + half of its row for the four MFMAs of step ks (channels 4 (2 ks + half) .. + 3).
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    constexpr int BUFF = (BM + BN) * 32;   // floats per buffer
-    const bool all_w = n0 + BN <= g.Nout;
-    auto stage = [&](int buf) {
-      float* const ab = smem + buf * BUFF;
-      float* const bb = ab + BM * 32;
-      const float* const xt = X + (ld_xoff + ld_ci * BKT);
-      const float* const wt = Wp + (ld_woff + ld_ci * BKT);
-      const unsigned m4 = (unsigned)(vmask[0] & 1ull) & (unsigned)(vmask[1] & 1ull) & (unsigned)(vmask[2] & 1ull) &
-                          (unsigned)(vmask[3] & 1ull);
-      if (__builtin_amdgcn_ballot_w64(m4 == 0u) == 0ull) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __builtin_amdgcn_global_load_lds((gptr_t)(xt + rowoff[i]), (lptr_t)(ab + (i * 32 + wave * 8) * 32), 16, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const void* src = (vmask[i] & 1ull) ? (const void*)(xt + rowoff[i]) : (const void*)g_zero_row;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ab + (i * 32 + wave * 8) * 32), 16, 0, 0);
-        }
-      }
-      if (all_w) {
-#pragma unroll
-        for (int i = 0; i < BN / 32; ++i)
-          __builtin_amdgcn_global_load_lds((gptr_t)(wt + wrow[i]), (lptr_t)(bb + (i * 32 + wave * 8) * 32), 16, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-          const void* src = wvalid[i] ? (const void*)(wt + wrow[i]) : (const void*)g_zero_row;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bb + (i * 32 + wave * 8) * 32), 16, 0, 0);
-        }
-      }
-      if (++ld_ci == kpt) {
-        ld_ci = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vmask[i] >>= 1;
-        if (++ld_tap < ntaps) tap_offsets(ld_tap);
-      }
-    };
-    const int swz = ((lane & 31) >> 1) & 7, hf = lane >> 5;
-    int ck[4];  // float offset of this lane's 16 bytes of step ks inside its (swizzled) row
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ck[ks] = (((2 * ks + hf) ^ swz) * 4);
-    const int arow = (wm * C::TM * 32 + (lane & 31)) * 32, brow = BM * 32 + (wn * C::TN * 32 + (lane & 31)) * 32;
-    stage(0);
-    for (int kt = 0; kt < KT; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < KT) stage((kt + 1) & 1);
-      const float* const tb = smem + (kt & 1) * BUFF;
-      f32x4 fa[2][C::TM], fb[2][C::TN];
-#pragma unroll
-      for (int i = 0; i < C::TM; ++i) fa[0][i] = *(const f32x4*)(tb + arow + i * 32 * 32 + ck[0]);
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) fb[0][j] = *(const f32x4*)(tb + brow + j * 32 * 32 + ck[0]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < 4) {
-#pragma unroll
-          for (int i = 0; i < C::TM; ++i) fa[nxt][i] = *(const f32x4*)(tb + arow + i * 32 * 32 + ck[ks + 1]);
-#pragma unroll
-          for (int j = 0; j < C::TN; ++j) fb[nxt][j] = *(const f32x4*)(tb + brow + j * 32 * 32 + ck[ks + 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][e], fb[cur][j][e], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();   // the epilogue reuses the arena
-  }
-
   const float* ap = As + (wm * C::TM * 32 + (lane & 31)) * LDK + (lane >> 5);
   const float* bp = Bs + (wn * C::TN * 32 + (lane & 31)) * LDK + (lane >> 5);
   constexpr int LDF = XH ? LDX : LDH;  // bf16 fragment row stride
   const __bf16* ahp = Ah + (wm * C::TM * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   const __bf16* bhp = Bh + (wn * C::TN * 32 + (lane & 31)) * LDF + 8 * (lane >> 5);
   // kt = -1 is the prologue: one call site for the gather keeps the pipeline uniform
-  for (int kt = -1; kt < (GLX ? -1 : KT); ++kt) {
+  for (int kt = -1; kt < (GL ? -1 : KT); ++kt) {
     if (kt + 1 < KT) load_tile(kt + 1);
     if (BF && kt >= 0) {
       // v_mfma_f32_32x32x16_bf16: lane (row = lane&31, half = lane>>5) feeds k = 8*half .. 8*half+7
@@ -2770,8 +2682,6 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
   const bool gl = XH && g.wh && gl_on;
   // exact-fp32 tiles with whole 32-channel K tiles: buffer loads (HP_IGEMM_BL=0 keeps the flat loads: A/B runs)
   static const bool bl_on = !(getenv("HP_IGEMM_BL") && atoi(getenv("HP_IGEMM_BL")) == 0);
-  // exact fp32: tiles straight into LDS (experiment: HP_IGEMM_GF=1)
-  static const bool gf_on = getenv("HP_IGEMM_GF") && atoi(getenv("HP_IGEMM_GF")) == 1;
   // (also the bf16 / split-bf16 modes on fp32 tensors: same loads, operands split on their way into LDS -- their flat
   // loads sat behind per-row branches and were waited for one by one)
   const bool bl = !XH && !g.xh && !g.wh && !STEM && bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 * (g.mode == MODE_DECONV ? 8 : 1) < (1l << 31);
@@ -2788,12 +2698,6 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
     }
     if constexpr (!XH && !STEM) {
       if (bl) {
-        if constexpr (NP == 0) {
-          if (gf_on) {
-            hipLaunchKernelGGL((k_igemm<128, false, STATS, 0, false, false, false, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
-            return;
-          }
-        }
         hipLaunchKernelGGL((k_igemm<128, false, STATS, NP, false, false, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
         return;
       }
@@ -2808,12 +2712,6 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
     }
     if constexpr (!XH && !STEM) {
       if (bl) {
-        if constexpr (NP == 0) {
-          if (gf_on) {
-            hipLaunchKernelGGL((k_igemm<64, false, STATS, 0, false, false, false, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
-            return;
-          }
-        }
         hipLaunchKernelGGL((k_igemm<64, false, STATS, NP, false, false, true>), dim3(mt, 1, classes), dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, g);
         return;
       }
