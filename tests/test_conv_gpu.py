@@ -96,14 +96,19 @@ def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims, precisio
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("zsplit", [1, 2])
+@pytest.mark.parametrize("zsplit", [1, 2, 0])
 def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch):
     """The stem's data gradient keeps its output patch as a ring of planes while a workgroup walks several 4-plane
-    patches along z (HP_STEM_DGRAD_ZSPLIT forces runs of 6 / 3 patches on this small volume; depth 22 ends in a partial
-    patch, H and W are not tile multiples).  fp32: the exact kernel; bf16: the patch GEMM on the bf16 matrix cores with
+    patches along z (HP_STEM_DGRAD_ZSPLIT forces runs of 6 / 3 patches on this small volume, 0 = the launcher's own choice;
+    depth 22 ends in a partial patch, H and W are not tile multiples: voxel rows outside the volume are fetched with
+    out-of-range buffer offsets, z slices outside with an empty descriptor; all 343 taps carry random weights, so the
+    49th tap row that rides in the spare columns of chunks 0..6 is checked like any other).  fp32: the exact kernel; bf16: the patch GEMM on the bf16 matrix cores with
     operands on the bf16 grid (exact products).  Also the stem forward (with its BatchNorm statistics) and the stem weight
     gradient of either mode on the same case."""
-    monkeypatch.setenv("HP_STEM_DGRAD_ZSPLIT", str(zsplit))
+    if zsplit:
+        monkeypatch.setenv("HP_STEM_DGRAD_ZSPLIT", str(zsplit))
+    else:
+        monkeypatch.delenv("HP_STEM_DGRAD_ZSPLIT", raising=False)   # the size heuristic: one patch per workgroup on this volume
     g = torch.Generator().manual_seed(77)
     B, D, H, W = 2, 22, 7, 11
     x = torch.randn(B, 1, D, H, W, generator=g)
