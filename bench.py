@@ -358,7 +358,13 @@ def bench_highres(args, emit=True, also_bf16=False):
     dconv_bf16 = getattr(args, "conv_precision", "fp32") in ("bf16", "bf16s")
     ops.set_dconv_precision("bf16" if dconv_bf16 else "fp32")
 
+    params = [p for m in (fe, fp, un) for p in m.parameters()]
+
     def step():
+        # gradients start from None, as after the training loop's optimizer.zero_grad(): otherwise every step also pays one
+        # tiny accumulation add per parameter (68 launches here) that no training step has
+        for p in params:
+            p.grad = None
         f = ops.normalize_feature(fp(fe(meas), [0] * B, [T] * B))
         r = un(f)
         (r.square().mean() + f.mean()).backward()
