@@ -665,10 +665,19 @@ __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
 
 __global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restrict__ z, float4* __restrict__ p, int B, int D,
                                                           int H, int W, int C4, const float4* __restrict__ sc,
-                                                          const float4* __restrict__ sh, VoxDecode vq, int c4_shift) {
+                                                          const float4* __restrict__ sh, VoxDecode vq, int c4_shift,
+                                                          unsigned xcd_group) {
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
   const long total = (long)B * Do * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
+  // Workgroup b runs on XCD b % 8, and neighbouring output rows share an input row: with the plain order the four 256-quad
+  // chunks of an output row land on four XCDs and every L2 fetches its own copy of the shared rows (2.25x the tensor through
+  // the fabric).  With xcd_group > 0 each XCD takes runs of xcd_group consecutive chunks of every round of gridDim.x chunks.
+  unsigned lb = blockIdx.x;
+  if (xcd_group > 0) {
+    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    lb = (slot / xcd_group) * (8u * xcd_group) + xcd * xcd_group + slot % xcd_group;
+  }
+  for (long i = (long)lb * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
     int c, ow, oh, od, b;
     if (vq.sw >= 0 && c4_shift >= 0) {  // pooled extents and C4 are powers of two: shifts instead of five divisions
       c = (int)(i & (C4 - 1));
@@ -1211,8 +1220,12 @@ extern "C" int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B
   hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 127) / 128), dim3(128), 0, st, mean, rstd, gamma, beta, C, sc, sh);
   HP_PROF("stem_bn_relu_pool_fwd", st);
   const long n = (long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(k_bn_relu_pool3_fwd, dim3(grid_for(n)), dim3(ET), 0, st, (const float4*)z, (float4*)pooled, B, D, H, W, C / 4,
-                     (const float4*)sc, (const float4*)sh, make_decode(D / 2, H / 2, W / 2), is_pow2(C / 4) ? ilog2(C / 4) : -1);
+  const unsigned grid = grid_for(n);
+  // runs of 32 chunks (eight 64-wide output rows of 64 channels) per XCD when the grid is whole rounds of such runs
+  unsigned xg = grid % 256 == 0 ? 32u : 0u;
+  if (const char* e = getenv("HP_POOL_XCD_GROUP")) xg = grid % (8u * (unsigned)std::max(1, atoi(e))) == 0 ? (unsigned)atoi(e) : 0u;
+  hipLaunchKernelGGL(k_bn_relu_pool3_fwd, dim3(grid), dim3(ET), 0, st, (const float4*)z, (float4*)pooled, B, D, H, W, C / 4,
+                     (const float4*)sc, (const float4*)sh, make_decode(D / 2, H / 2, W / 2), is_pow2(C / 4) ? ilog2(C / 4) : -1, xg);
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
 }
