@@ -672,26 +672,7 @@ __global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restri
   // Workgroup b runs on XCD b % 8, and neighbouring output rows share an input row: with the plain order the four 256-quad
   // chunks of an output row land on four XCDs and every L2 fetches its own copy of the shared rows (2.25x the tensor through
   // the fabric).  With xcd_group > 0 each XCD takes runs of xcd_group consecutive chunks of every round of gridDim.x chunks.
-  unsigned lb = blockIdx.x;
-  if (xcd_group > 0) {
-    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
-    lb = (slot / xcd_group) * (8u * xcd_group) + xcd * xcd_group + slot % xcd_group;
-  }
-  for (long i = (long)lb * ET + threadIdx.x; i < total; i += (long)gridDim.x * ET) {
-    int c, ow, oh, od, b;
-    if (vq.sw >= 0 && c4_shift >= 0) {  // pooled extents and C4 are powers of two: shifts instead of five divisions
-      c = (int)(i & (C4 - 1));
-      decode_vox(vq, i >> c4_shift, b, od, oh, ow);
-    } else {
-      c = (int)(i % C4);
-      long t = i / C4;
-      ow = (int)(t % Wo);
-      t /= Wo;
-      oh = (int)(t % Ho);
-      t /= Ho;
-      od = (int)(t % Do);
-      b = (int)(t / Do);
-    }
+  auto pool_one = [&](long i, int c, int ow, int oh, int od, int b) {
     const float4 a = sc[c], s0 = sh[c];
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // ReLU output is >= 0 and every window holds a valid voxel
     // A window position outside the volume is CLAMPED onto the border voxel, which the window holds anyway (the maximum does
@@ -717,6 +698,43 @@ __global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restri
       }
     }
     p[i] = m;
+  };
+  unsigned lb = blockIdx.x;
+  long stride = (long)gridDim.x * ET;
+  if (xcd_group == 0xffffffffu) {   // slab mode: XCD k walks the k-th eighth of the tensor, gridDim.x / 8 chunks at a time
+    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u, per = gridDim.x >> 3;
+    const long rounds = total / ((long)gridDim.x * ET);   // (the launcher checked: whole rounds)
+    lb = 0;
+    stride = (long)per * ET;
+    const long first = ((long)xcd * rounds * per + slot) * ET + threadIdx.x, last = (long)(xcd + 1) * rounds * per * ET;
+    for (long i = first; i < last; i += stride) {
+      int c, ow, oh, od, b;
+      c = (int)(i & (C4 - 1));
+      decode_vox(vq, i >> c4_shift, b, od, oh, ow);
+      pool_one(i, c, ow, oh, od, b);
+    }
+    return;
+  }
+  if (xcd_group > 0) {
+    const unsigned slot = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    lb = (slot / xcd_group) * (8u * xcd_group) + xcd * xcd_group + slot % xcd_group;
+  }
+  for (long i = (long)lb * ET + threadIdx.x; i < total; i += stride) {
+    int c, ow, oh, od, b;
+    if (vq.sw >= 0 && c4_shift >= 0) {  // pooled extents and C4 are powers of two: shifts instead of five divisions
+      c = (int)(i & (C4 - 1));
+      decode_vox(vq, i >> c4_shift, b, od, oh, ow);
+    } else {
+      c = (int)(i % C4);
+      long t = i / C4;
+      ow = (int)(t % Wo);
+      t /= Wo;
+      oh = (int)(t % Ho);
+      t /= Ho;
+      od = (int)(t % Do);
+      b = (int)(t / Do);
+    }
+    pool_one(i, c, ow, oh, od, b);
   }
 }
 
@@ -1224,6 +1242,7 @@ extern "C" int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B
   // runs of 32 chunks (eight 64-wide output rows of 64 channels) per XCD when the grid is whole rounds of such runs
   unsigned xg = grid % 256 == 0 ? 32u : 0u;
   if (const char* e = getenv("HP_POOL_XCD_GROUP")) xg = grid % (8u * (unsigned)std::max(1, atoi(e))) == 0 ? (unsigned)atoi(e) : 0u;
+  if (getenv("HP_POOL_XCD_SLAB") && grid % 8 == 0 && n % ((long)grid * ET) == 0 && is_pow2(C / 4) && make_decode(D / 2, H / 2, W / 2).sw >= 0) xg = 0xffffffffu;
   hipLaunchKernelGGL(k_bn_relu_pool3_fwd, dim3(grid), dim3(ET), 0, st, (const float4*)z, (float4*)pooled, B, D, H, W, C / 4,
                      (const float4*)sc, (const float4*)sh, make_decode(D / 2, H / 2, W / 2), is_pow2(C / 4) ? ilog2(C / 4) : -1, xg);
   HP_CHECK_HIP(hipGetLastError());
