@@ -17,6 +17,14 @@
 
 namespace hp {
 
+// Workgroup b of a launch runs on XCD b % 8 (each XCD has its own L2), and neighbouring (y, x) tiles share their halo rows
+// and columns: with the plain order no two neighbours ever meet in one L2.  Each XCD takes a contiguous eighth of the tile
+// list instead (whole launches of a multiple of 8 workgroups per grid row only, so that b % 8 is the XCD in every row).
+__device__ int g_xcd_slab = 1;
+__device__ __forceinline__ int xcd_slab_tile(unsigned b, unsigned n) {
+  return ((n & 7u) || !g_xcd_slab) ? (int)b : (int)((b & 7u) * (n >> 3) + (b >> 3));
+}
+
 
 // adjoint of replicate padding by 1: dx[p] = sum of the halo-domain cells that clamp to p.  grid (x tiles, H, nvol * D):
 // no index divisions, interior cells are one coalesced read; only the six faces sum 2 / 4 / 8 cells.
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   __shared__ float part[4][28 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = lane >> 2, sub = lane & 3;
-  int t_ = blockIdx.x;
+  int t_ = xcd_slab_tile(blockIdx.x, gridDim.x);
   const int bx = t_ % tiles_x;
   t_ /= tiles_x;
   const int by = t_ % tiles_y;
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __res
   __shared__ float part[4][28 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = lane >> 2, sub = lane & 3;
-  int t_ = blockIdx.x;
+  int t_ = xcd_slab_tile(blockIdx.x, gridDim.x);
   const int bx = t_ % tiles_x;
   t_ /= tiles_x;
   const int by = t_ % tiles_y;
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   __shared__ float part[4][28 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int blk = lane >> 2, sub = lane & 3;
-  int t_ = blockIdx.x;
+  int t_ = xcd_slab_tile(blockIdx.x, gridDim.x);
   const int bx = t_ % tiles_x;
   t_ /= tiles_x;
   const int by = t_ % tiles_y;
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float wl[4 * 4 * 28];  // [ci][co][28]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3;
-  int t_ = blockIdx.x;
+  int t_ = xcd_slab_tile(blockIdx.x, gridDim.x);
   const int bx = t_ % tiles_x;
   t_ /= tiles_x;
   const int by = t_ % tiles_y;
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
   f32x4 st1v = {0.f, 0.f, 0.f, 0.f}, st2v = {0.f, 0.f, 0.f, 0.f};   // per-channel sum / sum of squares of this lane's outputs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3;
-  int t_ = blockIdx.x;
+  int t_ = xcd_slab_tile(blockIdx.x, gridDim.x);
   const int bx = t_ % tiles_x;
   t_ /= tiles_x;
   const int by = t_ % tiles_y;
@@ -1369,7 +1377,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_f16(const float* __restrict__
   __shared__ float sred[4][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 4, ln = lane & 15;  // K slot / column (A: row = ln) of this lane's operands
-  int t_ = blockIdx.x;
+  int t_ = xcd_slab_tile(blockIdx.x, gridDim.x);
   const int bx = t_ % tiles_x;
   t_ /= tiles_x;
   const int by = t_ % tiles_y;
@@ -1864,9 +1872,22 @@ static bool use_f16_dconv() {
   return v;
 }
 
+// HP_DCONV_XCD_SLAB=0 keeps the plain tile order (A/B runs)
+static void xcd_slab_init() {
+  static const bool done = [] {
+    if (const char* e = getenv("HP_DCONV_XCD_SLAB")) {
+      const int v = atoi(e) != 0;
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_slab), &v, sizeof(int));
+    }
+    return true;
+  }();
+  (void)done;
+}
+
 static int run_dconv(const float* x, const float* w, const float* bias, const float* res, float* y, double* stats, float slope,
                      int B, int cin, int cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int pad, long wsco, long wsci,
                      int flip, int padmode, hipStream_t st, int precision = HP_PRECISION_FP32) {
+  xcd_slab_init();
   // the kernels address a 4-channel group of planes through one buffer descriptor (31-bit byte offsets: beyond it loads read
   // zero and stores are dropped)
   HP_REQUIRE((long)Di * Hi * Wi * 16 < (1l << 31) && (long)Do * Ho * Wo * 16 < (1l << 31),
@@ -2078,6 +2099,7 @@ extern "C" int hp_dconv3_backward_weight(const float* x, const float* gy, float*
 extern "C" int hp_dconv3_backward_weight_p(const float* x, const float* gy, float* dw, float* dbias, int B, int cin,
                                            int cout, int D, int H, int W, int replicate_pad, int precision, void* workspace,
                                            void* stream) {
+  xcd_slab_init();
   HP_REQUIRE(x && gy && dw && workspace && B > 0, "hp_dconv3_backward_weight: bad argument");
   HP_REQUIRE(precision == HP_PRECISION_FP32 || precision == HP_PRECISION_BF16, "hp_dconv3_backward_weight_p: precision must be fp32 or bf16");
   hipStream_t st = (hipStream_t)stream;
