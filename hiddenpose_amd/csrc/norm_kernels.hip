@@ -669,9 +669,10 @@ __global__ __launch_bounds__(ET) void k_bn_relu_pool3_fwd(const float4* __restri
                                                           unsigned xcd_group) {
   const int Do = D / 2, Ho = H / 2, Wo = W / 2;
   const long total = (long)B * Do * Ho * Wo * C4;
-  // Workgroup b runs on XCD b % 8, and neighbouring output rows share an input row: with the plain order the four 256-quad
-  // chunks of an output row land on four XCDs and every L2 fetches its own copy of the shared rows (2.25x the tensor through
-  // the fabric).  With xcd_group > 0 each XCD takes runs of xcd_group consecutive chunks of every round of gridDim.x chunks.
+  // Workgroup b runs on XCD b % 8, and neighbouring output rows / planes share input rows / planes: with the plain order the
+  // four 256-quad chunks of an output row land on four XCDs and every L2 fetches its own copy of the shared rows (2.25x the
+  // tensor through the fabric).  xcd_group = 0xffffffff: each XCD walks a contiguous eighth of the pooled tensor (3.06 ->
+  // 2.41 ms at 4 x 512 x 128 x 128 x 64); 0 < xcd_group: runs of xcd_group chunks per XCD in every round of gridDim.x chunks.
   auto pool_one = [&](long i, int c, int ow, int oh, int od, int b) {
     const float4 a = sc[c], s0 = sh[c];
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // ReLU output is >= 0 and every window holds a valid voxel
@@ -847,7 +848,8 @@ __global__ __launch_bounds__(ET) void k_stem_bwd_tiled(const float4* __restrict_
                                                        const float4* __restrict__ dp, float4* __restrict__ dz, int B, int D,
                                                        int H, int W, const float4* __restrict__ sc, const float4* __restrict__ sh,
                                                        const float4* __restrict__ k0, const float4* __restrict__ k1,
-                                                       const float4* __restrict__ k2, double* __restrict__ red, long ntiles) {
+                                                       const float4* __restrict__ k2, double* __restrict__ red, long ntiles,
+                                                       int xcd_slab) {
   constexpr int C4 = 16;
   __shared__ float4 sp[2 * 2 * ST_HALO * C4], sg[2 * 2 * ST_HALO * C4];
   const int tid = threadIdx.x, cq = tid & (C4 - 1), vrow = tid >> 4;  // 16 voxel slots x 16 channel quads
@@ -856,7 +858,13 @@ __global__ __launch_bounds__(ET) void k_stem_bwd_tiled(const float4* __restrict_
   // reduce: k0 = mean, k1 = rstd;  apply: k0 = ca, k1 = cb, k2 = cc
   const float4 q0 = k0[cq], q1 = k1[cq], q2 = APPLY ? k2[cq] : make_float4(0, 0, 0, 0);
   float4 s = make_float4(0, 0, 0, 0), dd = make_float4(0, 0, 0, 0);
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // XCD-aware walk (workgroup b runs on XCD b % 8): neighbouring tiles share their pooled windows, so each XCD takes a
+  // contiguous eighth of the tile list (whole eighths only) and its L2 serves the shared windows
+  const bool slab = xcd_slab && (ntiles & 7) == 0 && (gridDim.x & 7u) == 0;
+  const long t_first = slab ? (long)(blockIdx.x & 7u) * (ntiles >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+  const long t_last = slab ? (long)((blockIdx.x & 7u) + 1) * (ntiles >> 3) : ntiles;
+  const long t_step = slab ? (long)(gridDim.x >> 3) : (long)gridDim.x;
+  for (long tile = t_first; tile < t_last; tile += t_step) {
     long t = tile;
     const int wt = (int)(t % tw);
     t /= tw;
@@ -1239,10 +1247,14 @@ extern "C" int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B
   HP_PROF("stem_bn_relu_pool_fwd", st);
   const long n = (long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
   const unsigned grid = grid_for(n);
-  // runs of 32 chunks (eight 64-wide output rows of 64 channels) per XCD when the grid is whole rounds of such runs
-  unsigned xg = grid % 256 == 0 ? 32u : 0u;
-  if (const char* e = getenv("HP_POOL_XCD_GROUP")) xg = grid % (8u * (unsigned)std::max(1, atoi(e))) == 0 ? (unsigned)atoi(e) : 0u;
-  if (getenv("HP_POOL_XCD_SLAB") && grid % 8 == 0 && n % ((long)grid * ET) == 0 && is_pow2(C / 4) && make_decode(D / 2, H / 2, W / 2).sw >= 0) xg = 0xffffffffu;
+  // slab order (each XCD walks a contiguous eighth of the pooled tensor) when the launch is whole rounds and the extents
+  // decode with shifts; otherwise runs of 32 chunks per XCD and round, or the plain order.  HP_POOL_XCD_SLAB=0: plain (A/B runs)
+  static const bool xslab = !(getenv("HP_POOL_XCD_SLAB") && atoi(getenv("HP_POOL_XCD_SLAB")) == 0);
+  unsigned xg = 0u;
+  if (xslab) {
+    if (grid % 8 == 0 && n % ((long)grid * ET) == 0 && is_pow2(C / 4) && make_decode(D / 2, H / 2, W / 2).sw >= 0) xg = 0xffffffffu;
+    else if (grid % 256 == 0) xg = 32u;
+  }
   hipLaunchKernelGGL(k_bn_relu_pool3_fwd, dim3(grid), dim3(ET), 0, st, (const float4*)z, (float4*)pooled, B, D, H, W, C / 4,
                      (const float4*)sc, (const float4*)sh, make_decode(D / 2, H / 2, W / 2), is_pow2(C / 4) ? ilog2(C / 4) : -1, xg);
   HP_CHECK_HIP(hipGetLastError());
@@ -1268,11 +1280,12 @@ extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled
   const int C4 = C / 4;
   const bool tiled = C == 64 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0;
   const long ntiles = (long)B * (D / 2) * (H / 2) * ((W + ST_W - 1) / ST_W);
+  static const int xslab = !(getenv("HP_POOL_XCD_SLAB") && atoi(getenv("HP_POOL_XCD_SLAB")) == 0);   // 0: plain order (A/B runs)
   if (tiled) {
     HP_PROF("stem_bn_pool_bwd_reduce", st);
     hipLaunchKernelGGL(k_stem_bwd_tiled<false>, dim3((unsigned)std::min<long>(ntiles, 256 * 8)), dim3(ET), 0, st, (const float4*)z,
                        (const float4*)pooled, (const float4*)dpooled, (float4*)nullptr, B, D, H, W, (const float4*)sc,
-                       (const float4*)sh, (const float4*)mean, (const float4*)rstd, (const float4*)nullptr, red, ntiles);
+                       (const float4*)sh, (const float4*)mean, (const float4*)rstd, (const float4*)nullptr, red, ntiles, xslab);
   } else {
     HP_PROF("stem_bn_pool_bwd_reduce", st);
     const int vpb = ET / C4;
@@ -1286,7 +1299,7 @@ extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled
     HP_PROF("stem_bn_pool_bwd_apply", st);
     hipLaunchKernelGGL(k_stem_bwd_tiled<true>, dim3((unsigned)std::min<long>(ntiles, 256 * 64)), dim3(ET), 0, st, (const float4*)z,
                        (const float4*)pooled, (const float4*)dpooled, (float4*)dz, B, D, H, W, (const float4*)sc, (const float4*)sh,
-                       (const float4*)ca, (const float4*)cb, (const float4*)cc, (double*)nullptr, ntiles);
+                       (const float4*)ca, (const float4*)cb, (const float4*)cc, (double*)nullptr, ntiles, xslab);
   } else {
     HP_PROF("stem_bn_pool_bwd_apply", st);
     hipLaunchKernelGGL(k_stem_bwd_apply, dim3(grid_for(nvox * C4)), dim3(ET), 0, st, (const float4*)z, (const float4*)pooled,

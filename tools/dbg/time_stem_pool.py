@@ -22,3 +22,11 @@ def timeit(fn, n=5):
 t = timeit(fwd)
 gb = (z.numel() + p.numel()) * 4 / 1e9
 print(f"stem bn+relu+pool fwd {B}x{D}x{H}x{W}: {t:.3f} ms  {gb / t:.2f} TB/s (z once + pooled)   checksum {float(p.double().sum()):.6e}")
+dp = torch.randn_like(p); dz = torch.empty_like(z)
+dgamma = torch.empty(C, device='cuda'); dbeta = torch.empty(C, device='cuda')
+def bwd():
+    _lib.check(L.hp_stem_bn_relu_pool_backward(z.data_ptr(), p.data_ptr(), dp.data_ptr(), dz.data_ptr(), B, D, H, W, C, mean.data_ptr(), rstd.data_ptr(),
+                                               gamma.data_ptr(), beta.data_ptr(), 1, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), st), "bwd")
+fwd()
+t = timeit(bwd)
+print(f"stem bn+relu+pool bwd (reduce + apply): {t:.3f} ms   checksum {float(dz.double().abs().sum()):.6e} {float(dgamma.double().sum()):.6e}")
