@@ -59,6 +59,7 @@ struct IgemmGeom {
   int wh;                  // packed weights are bf16 (bf16-storage tiles only)
   int geglu;               // 1: GEGLU epilogue (hp_linear_geglu_forward): columns [0, 64) of every 128-column tile are values, [64, 128)
                            //    their gates; Y has Nout / 2 columns and receives value * gelu(gate)
+  int slab;                // > 0: M tiles per XCD -- XCD k (workgroup b runs on XCD b % 8) walks M tiles k * slab .. (k + 1) * slab - 1
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   if (g.tn > 0) {
     const unsigned i = blockIdx.x >> 3;
     nt_idx = i % (unsigned)g.tn;
-    mt_idx = (i / (unsigned)g.tn) * 8u + (blockIdx.x & 7u);
+    mt_idx = g.slab > 0 ? (blockIdx.x & 7u) * (unsigned)g.slab + i / (unsigned)g.tn : (i / (unsigned)g.tn) * 8u + (blockIdx.x & 7u);
+    if ((long)mt_idx * BM >= g.M) return;
+  } else if (g.slab > 0) {
+    mt_idx = (blockIdx.x & 7u) * (unsigned)g.slab + (blockIdx.x >> 3);
     if ((long)mt_idx * BM >= g.M) return;
   }
   const long m0 = (long)mt_idx * BM;
@@ -2685,11 +2689,25 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
   // (also the bf16 / split-bf16 modes on fp32 tensors: same loads, operands split on their way into LDS -- their flat
   // loads sat behind per-row branches and were waited for one by one)
   const bool bl = !XH && !g.xh && !g.wh && !STEM && bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 * (g.mode == MODE_DECONV ? 8 : 1) < (1l << 31);
+  // experiment: each XCD walks a contiguous eighth of the M tiles (HP_IGEMM_SLAB=1)
+  static const bool slab_on = getenv("HP_IGEMM_SLAB") && atoi(getenv("HP_IGEMM_SLAB")) == 1;
+  if (slab_on && g.Nout <= 64) {
+    IgemmGeom gs = g;
+    gs.slab = (int)((mt + 7) / 8);
+    const dim3 grid((mt + 7) / 8 * 8, 1, classes);
+    if constexpr (!XH && !STEM) {
+      if (bl && g.Nout > 32) {
+        hipLaunchKernelGGL((k_igemm<64, false, STATS, NP, false, false, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gs);
+        return;
+      }
+    }
+  }
   if (g.Nout > 64) {
     const unsigned tn = (unsigned)((g.Nout + 127) / 128);
     IgemmGeom gg = g;
     gg.tn = tn > 1 ? (int)tn : 0;  // XCD-aware 1-D grid (see k_igemm)
-    const dim3 grid = tn > 1 ? dim3((mt + 7) / 8 * 8 * tn, 1, classes) : dim3(mt, 1, classes);
+    gg.slab = slab_on ? (int)((mt + 7) / 8) : 0;
+    const dim3 grid = (tn > 1 || gg.slab) ? dim3((mt + 7) / 8 * 8 * (tn > 1 ? tn : 1), 1, classes) : dim3(mt, 1, classes);
     if constexpr (XH) {
       if (gl) {
         hipLaunchKernelGGL((k_igemm<128, STEM, STATS, NP, true, true>), grid, dim3(CT), 0, st, X, W, bias, Y, stats, addend, amask, gg);
