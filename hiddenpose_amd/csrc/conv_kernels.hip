@@ -2689,8 +2689,10 @@ static void launch_igemm_bn(const IgemmGeom& g, int classes, const void* X, cons
   // (also the bf16 / split-bf16 modes on fp32 tensors: same loads, operands split on their way into LDS -- their flat
   // loads sat behind per-row branches and were waited for one by one)
   const bool bl = !XH && !g.xh && !g.wh && !STEM && bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 * (g.mode == MODE_DECONV ? 8 : 1) < (1l << 31);
-  // experiment: each XCD walks a contiguous eighth of the M tiles (HP_IGEMM_SLAB=1)
-  static const bool slab_on = getenv("HP_IGEMM_SLAB") && atoi(getenv("HP_IGEMM_SLAB")) == 1;
+  // each XCD walks a contiguous eighth of the M tiles: the halo rows / planes that neighbouring M tiles share are then served
+  // by ONE L2 instead of being fetched by several (same step time, L2 fills of the family 422 -> 383 GB per headline step on
+  // one device).  HP_IGEMM_SLAB=0: M tile m on XCD m % 8 as before (A/B runs)
+  static const bool slab_on = !(getenv("HP_IGEMM_SLAB") && atoi(getenv("HP_IGEMM_SLAB")) == 0);
   if (slab_on && g.Nout <= 64) {
     IgemmGeom gs = g;
     gs.slab = (int)((mt + 7) / 8);
