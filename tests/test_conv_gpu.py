@@ -95,6 +95,22 @@ def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims, precisio
     assert rel_l2(dw, wd.grad) < tol_g
 
 
+def test_stem_data_gradient_interior_and_edge_patches():
+    """The stem's data gradient on a volume with whole interior patches next to partial ones in every direction
+    (4 x 4 x 8-voxel patches on 13 x 18 x 43 voxels, two samples, the launcher's own z split), all 343 taps random:
+    against float64 autograd."""
+    g = torch.Generator().manual_seed(78)
+    B, D, H, W = 2, 13, 18, 43
+    w = torch.randn(64, 1, 7, 7, 7, generator=g) / np.sqrt(343.0)
+    gy = torch.randn(B, 64, D, H, W, generator=g)
+    xd = torch.zeros(B, 1, D, H, W, dtype=torch.float64, requires_grad=True)
+    (F.conv3d(xd, w.double(), padding=3) * gy.double()).sum().backward()
+    xc = cl(torch.zeros(B, 1, D, H, W)).cuda()
+    desc = ops._desc(xc, 64, 7, 1, 3, False)
+    dx, _ = ops._conv_grads(desc, xc, w.cuda(), cl(gy).cuda(), True)
+    assert rel_l2(ncdhw(dx), xd.grad) < 5e-6
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("zsplit", [1, 2, 0])
 def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch):
