@@ -46,6 +46,7 @@ SIGNATURES = {
     "hp_conv3d_backward_data": (_i, [_vp, _fp, _fp, _fp, _fp, _vp]),
     "hp_conv3d_backward_data_masked": (_i, [_vp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_conv3d_backward_weight": (_i, [_vp, _fp, _fp, _fp, _vp]),
+    "hp_conv3d_backward_weight_split": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "hp_bn_train_finalize": (_i, [_vp, C.c_long, _i, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _vp]),
     "hp_bn_train_finalize_counted": (_i, [_vp, C.c_long, _i, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_bn_eval_stats": (_i, [_fp, _fp, _i, C.c_float, _fp, _fp, _vp]),

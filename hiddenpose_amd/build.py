@@ -1,6 +1,7 @@
 """In-tree build of libhiddenpose_hip.so for gfx950 (hipcc cross-compiles without a GPU).
 
     python -m hiddenpose_amd.build [--force]
+    python -m hiddenpose_amd.build --asan-host     # test-only: the HIP-free host sources under ASan + UBSan (see below)
 
 Objects go to hiddenpose_amd/csrc/build/, the library next to this file so that it
 travels with the source snapshot to the GPU box.
@@ -76,5 +77,45 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+# SURVEY section 5's safety net for the host code: the translation units that touch no device (the error string, the LCT
+# constant builder and the Radiance container parser, which reads UNTRUSTED file bytes) compiled by the plain host compiler
+# with AddressSanitizer + UndefinedBehaviorSanitizer into a test-only library.  tests/test_host_asan.py loads it in a child
+# process (libasan preloaded) and runs the host ABI tests and a fuzz loop against it.  No device code, no HIP runtime.
+HOST_ONLY = ["hp_error.cpp", "lct_host.cpp", "rgbe_host.cpp"]
+ASAN_LIB = os.path.join(OBJ, "libhiddenpose_host_asan.so")
+HOSTCXX = os.environ.get("HOSTCXX", "g++")
+
+
+def build_asan_host(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in HOST_ONLY]
+    deps = srcs + sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    if not force and os.path.exists(ASAN_LIB) and os.path.getmtime(ASAN_LIB) >= max(os.path.getmtime(d) for d in deps):
+        return ASAN_LIB
+    cmd = [HOSTCXX, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+           "-I", CSRC, "-o", ASAN_LIB] + srcs + ["-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host sanitizer build failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {ASAN_LIB} ({os.path.getsize(ASAN_LIB)/1e6:.1f} MB) from {len(srcs)} host-only sources")
+    return ASAN_LIB
+
+
+def sanitizer_runtime() -> str:
+    """Paths of libasan / libubsan for LD_PRELOAD (a sanitized library in an unsanitized python needs its runtime first)."""
+    out = []
+    for name in ("libasan.so", "libubsan.so"):
+        r = subprocess.run([HOSTCXX, f"-print-file-name={name}"], capture_output=True, text=True)
+        path = r.stdout.strip()
+        if r.returncode == 0 and os.path.isabs(path) and os.path.exists(path):
+            out.append(os.path.realpath(path))
+    return ":".join(out)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--asan-host" in sys.argv:
+        build_asan_host(force="--force" in sys.argv)
+    else:
+        build(force="--force" in sys.argv)

@@ -2974,6 +2974,42 @@ extern "C" int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void*
   return HP_OK;
 }
 
+// How the generic weight-gradient kernels split one call: TT x TT tiles of dW[Cout][K], tap groups, and `msplit` chunks of
+// the M = B * voxels reduction whose partial sums meet in fp32 atomics.
+struct WgradSplit {
+  int TT, tap_groups, tiles_c, tiles_total;
+  bool multitap;
+  long msplit;
+};
+static WgradSplit wgrad_split(const ConvPlan& p) {
+  const IgemmGeom& g = p.wgrad;
+  const int Kc = p.stem ? g.kpt * BK : g.Cin;
+  WgradSplit w{};
+  w.TT = (g.Nout >= 128 && Kc >= 128) ? 128 : 64;
+  // 64-wide tiles of a plain 3^3 convolution: 4 taps per block share the staged dY tile
+  w.multitap = !p.stem && w.TT == 64 && g.mode == MODE_CONV && g.k == 3;
+  w.tap_groups = w.multitap ? (27 + 3) / 4 : p.wgrad_tapsum;
+  const int tiles_n = (g.Nout + w.TT - 1) / w.TT;
+  w.tiles_c = (Kc + w.TT - 1) / w.TT;
+  const long base_blocks = (long)tiles_n * w.tiles_c * w.tap_groups;
+  long msplit = std::max<long>(1, (4096 + base_blocks - 1) / base_blocks);
+  msplit = std::min<long>(msplit, std::max<long>(1, g.M / (4 * WG_KM)));
+  w.msplit = std::min<long>(msplit, 4096);
+  w.tiles_total = tiles_n * w.tiles_c;
+  return w;
+}
+
+extern "C" int hp_conv3d_backward_weight_split(const hp_conv_desc* d, long* msplit, long* chunk_rows) {
+  HP_REQUIRE(d && msplit && chunk_rows, "hp_conv3d_backward_weight_split: null argument");
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  const WgradSplit ws = wgrad_split(p);
+  *msplit = ws.msplit;
+  *chunk_rows = ((p.wgrad.M + ws.msplit - 1) / ws.msplit + WG_KM - 1) / WG_KM * WG_KM;  // as the kernels round it
+  return HP_OK;
+}
+
 extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, const void* dy, float* dw_packed,
                                          void* stream) {
   HP_REQUIRE(d && x && dy && dw_packed, "hp_conv3d_backward_weight: null argument");
@@ -3018,16 +3054,10 @@ extern "C" int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, c
       return HP_OK;
     }
   }
-  const int TT = (g.Nout >= 128 && Kc >= 128) ? 128 : 64;
-  // 64-wide tiles of a plain 3^3 convolution: 4 taps per block share the staged dY tile
-  const bool multitap = !p.stem && TT == 64 && g.mode == MODE_CONV && g.k == 3;
-  const int tap_groups = multitap ? (27 + 3) / 4 : p.wgrad_tapsum;
-  const int tiles_n = (g.Nout + TT - 1) / TT, tiles_c = (Kc + TT - 1) / TT;
-  const long base_blocks = (long)tiles_n * tiles_c * tap_groups;
-  long msplit = std::max<long>(1, (4096 + base_blocks - 1) / base_blocks);
-  msplit = std::min<long>(msplit, std::max<long>(1, g.M / (4 * WG_KM)));
-  msplit = std::min<long>(msplit, 4096);
-  const int tiles_total = tiles_n * tiles_c;
+  const WgradSplit ws = wgrad_split(p);
+  const int TT = ws.TT, tap_groups = ws.tap_groups, tiles_c = ws.tiles_c, tiles_total = ws.tiles_total;
+  const bool multitap = ws.multitap;
+  const long msplit = ws.msplit;
   dim3 grid((unsigned)((long)tiles_total * tap_groups * msplit));
   {
     HP_PROF("conv_wgrad", st);

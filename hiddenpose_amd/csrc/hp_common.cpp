@@ -1,23 +1,10 @@
-// Error string + version entry points of the C ABI (include/hiddenpose_hip.h).
+// Per-kernel HIP-event timing of the C ABI (hp_profile_*, include/hiddenpose_hip.h); error string and version: hp_error.cpp.
 #include "hp_internal.h"
 
 #include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
-
-namespace hp {
-static thread_local std::string g_last_error;
-
-void set_error(const char* fmt, ...) {
-  char buf[1024];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_last_error = buf;
-}
-}  // namespace hp
 
 namespace hp {
 namespace {
@@ -107,6 +94,3 @@ extern "C" int hp_profile_get(int i, char* name, int name_cap, int64_t* launches
   return HP_OK;
 }
 
-extern "C" int hp_version(void) { return 100; }
-
-extern "C" const char* hp_last_error_string(void) { return hp::g_last_error.c_str(); }

@@ -2,15 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <cstdarg>
-#include <cstdio>
-#include <string>
-
-#include "hiddenpose_hip.h"
+#include "hp_host.h"
 
 namespace hp {
-
-void set_error(const char* fmt, ...);
 
 #define HP_CHECK_HIP(expr)                                                              \
   do {                                                                                  \
@@ -19,14 +13,6 @@ void set_error(const char* fmt, ...);
       ::hp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
       return HP_ERR_HIP;                                                                \
     }                                                                                   \
-  } while (0)
-
-#define HP_REQUIRE(cond, ...)          \
-  do {                                 \
-    if (!(cond)) {                     \
-      ::hp::set_error(__VA_ARGS__);    \
-      return HP_ERR_BAD_ARG;           \
-    }                                  \
   } while (0)
 
 // Optional per-kernel timing with HIP events on the launch stream (hp_profile_* in the C ABI).
@@ -79,12 +65,5 @@ __device__ __forceinline__ void hp_st1(void* p, long i, float v, int half) {
   else reinterpret_cast<float*>(p)[i] = v;
 }
 #endif
-
-inline int ilog2(int v) {
-  int l = 0;
-  while ((1 << l) < v) ++l;
-  return l;
-}
-inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace hp

@@ -4,7 +4,7 @@
 // /max -> (600,256,256)[:512] -> pairwise time average -> DAWNSAMPLE_CNT rounds of 2x2x2 box averaging --
 // and the same box pyramid for the ground-truth volume and for utils/loadrealdata.py:6-15.
 //
-// Host side (file parsing, no arithmetic): header + run-length expansion of the .hdr into flat RGBE bytes.
+// Host side (file parsing, no arithmetic): header + run-length expansion of the .hdr into flat RGBE bytes (rgbe_host.cpp).
 // Device side: two max reductions over the whole image (both normalisations are global) and ONE fused
 // pass that decodes, normalises, converts to gray, crops and averages: every output voxel reads its
 // 2^(cnt+1) x 2^cnt x 2^cnt pixels straight from the RGBE bytes (4 B/pixel) and nothing intermediate is
@@ -149,46 +149,6 @@ __global__ __launch_bounds__(256) void k_pair_avg(const float* __restrict__ in, 
   out[i] = __fmul_rn(__fadd_rn(p[0], p[sd]), 0.5f);
 }
 
-// ---------------------------------------------------------------- host: Radiance .hdr container
-struct Cursor {
-  const uint8_t* p;
-  const uint8_t* end;
-  bool line(std::string& out) {
-    out.clear();
-    while (p < end && *p != '\n') out.push_back((char)*p++);
-    if (p >= end) return false;
-    ++p;
-    return true;
-  }
-};
-
-static int parse_header(Cursor& c, int& W, int& H) {
-  std::string ln;
-  if (!c.line(ln) || ln.size() < 2 || ln[0] != '#' || ln[1] != '?') {
-    set_error("rgbe: missing '#?' signature line");
-    return HP_ERR_BAD_ARG;
-  }
-  bool fmt = false;
-  for (;;) {
-    if (!c.line(ln)) {
-      set_error("rgbe: header ends before the blank line");
-      return HP_ERR_BAD_ARG;
-    }
-    if (ln.empty()) break;
-    if (ln == "FORMAT=32-bit_rle_rgbe") fmt = true;
-  }
-  if (!fmt) {
-    set_error("rgbe: FORMAT=32-bit_rle_rgbe line not found");
-    return HP_ERR_BAD_ARG;
-  }
-  if (!c.line(ln) || std::sscanf(ln.c_str(), "-Y %d +X %d", &H, &W) != 2 || W < 1 || H < 1) {
-    set_error("rgbe: only the standard '-Y H +X W' orientation is supported (got '%s')", ln.c_str());
-    return HP_ERR_UNSUPPORTED;
-  }
-  return HP_OK;
-}
-
-
 // ---------------------------------------------------------------- noise variant (utils/nlos_pose_dataloader_noise.py:86-118)
 // The noise dataset converts the RAW float image to gray (its first "/ max" is commented out, :92), perturbs it
 // (addnoise_dataset: hp_noise_blur_poisson) and only then normalises by the global maximum of the noisy image, so the gray
@@ -252,56 +212,6 @@ __global__ __launch_bounds__(256) void k_image_to_meas(const float* __restrict__
 }  // namespace hp
 
 using namespace hp;
-
-extern "C" int hp_rgbe_decode(const unsigned char* file, size_t nbytes, int* width, int* height, unsigned char* rgbe,
-                              size_t rgbe_capacity) {
-  HP_REQUIRE(file && width && height, "hp_rgbe_decode: null argument");
-  Cursor c{file, file + nbytes};
-  int W = 0, H = 0;
-  int rc = parse_header(c, W, H);
-  if (rc) return rc;
-  *width = W;
-  *height = H;
-  if (!rgbe) return HP_OK;  // size query
-  const size_t need = (size_t)W * H * 4;
-  HP_REQUIRE(rgbe_capacity >= need, "hp_rgbe_decode: output buffer holds %zu bytes, %zu needed", rgbe_capacity, need);
-  std::string scan((size_t)W * 4, '\0');
-  for (int y = 0; y < H; ++y) {
-    uint8_t* dst = rgbe + (size_t)y * W * 4;
-    HP_REQUIRE(c.end - c.p >= 4, "rgbe: file ends in scanline %d", y);
-    const bool rle = W >= 8 && W < 32768 && c.p[0] == 2 && c.p[1] == 2 && !(c.p[2] & 0x80);
-    if (!rle) {
-      // flat pixels: the rest of the file is uncompressed (the decision is taken at the first such scanline)
-      const size_t rest = (size_t)(H - y) * W * 4;
-      HP_REQUIRE((size_t)(c.end - c.p) >= rest, "rgbe: file ends inside the flat pixel block");
-      std::memcpy(dst, c.p, rest);
-      return HP_OK;
-    }
-    HP_REQUIRE(((c.p[2] << 8) | c.p[3]) == W, "rgbe: scanline %d has a wrong width", y);
-    c.p += 4;
-    for (int ch = 0; ch < 4; ++ch) {
-      int x = 0;
-      while (x < W) {
-        HP_REQUIRE(c.end - c.p >= 2, "rgbe: file ends in scanline %d", y);
-        int cnt = *c.p++;
-        if (cnt > 128) {
-          cnt -= 128;
-          HP_REQUIRE(cnt > 0 && x + cnt <= W, "rgbe: bad run in scanline %d", y);
-          const uint8_t v = *c.p++;
-          for (int i = 0; i < cnt; ++i) scan[(size_t)ch * W + x++] = (char)v;
-        } else {
-          HP_REQUIRE(cnt > 0 && x + cnt <= W && c.end - c.p >= cnt, "rgbe: bad literal block in scanline %d", y);
-          std::memcpy(&scan[(size_t)ch * W + x], c.p, (size_t)cnt);
-          c.p += cnt;
-          x += cnt;
-        }
-      }
-    }
-    for (int x = 0; x < W; ++x)
-      for (int ch = 0; ch < 4; ++ch) dst[(size_t)x * 4 + ch] = (uint8_t)scan[(size_t)ch * W + x];
-  }
-  return HP_OK;
-}
 
 extern "C" int hp_ingest_rgbe_to_meas(const unsigned char* rgbe, int frames, int H, int W, int keep_frames,
                                       int downsample_cnt, float* meas, float* maxima, void* stream) {

@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
+
+#include "hp_host.h"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -197,3 +200,41 @@ void lct_invpsf_slice(const LctHost& h, int kz, std::complex<double>* out, std::
 }
 
 }  // namespace hp
+
+using namespace hp;
+
+// The constants as dense arrays for tests and for hosts that want them without a device (HIP-free).
+extern "C" int hp_lct_host_constants(int T, int N, double bin_len, double wall_size, float* gridz, float* mtx,
+                                     int32_t* psf_zidx, int64_t* psf_count, float* invpsf_re, float* invpsf_im) {
+  HP_REQUIRE(is_pow2(T) && T >= 2 && N >= 1, "hp_lct_host_constants: T must be a power of two, N >= 1");
+  LctHost h;
+  lct_host_build(T, N, bin_len, wall_size, h);
+  if (gridz) std::memcpy(gridz, h.gridz.data(), sizeof(float) * T);
+  if (mtx) {
+    std::memset(mtx, 0, sizeof(float) * (size_t)T * T);
+    for (int r = 0; r < T; ++r)
+      for (int e = h.mtx.off[r]; e < h.mtx.off[r + 1]; ++e) mtx[(size_t)r * T + h.mtx.idx[e]] = h.mtx.val[e];
+  }
+  const int N2 = 2 * N, M2 = 2 * T;
+  if (psf_zidx)
+    for (int p = 0; p < N2 * N2; ++p) psf_zidx[p] = h.mark_off[p + 1] > h.mark_off[p] ? h.mark_z[h.mark_off[p]] : -1;
+  if (psf_count) *psf_count = h.count;
+  if (invpsf_re && invpsf_im) {
+    const size_t sl = (size_t)N2 * N2;
+    unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; ++t)
+      th.emplace_back([&, t]() {
+        std::vector<std::complex<double>> buf(sl);
+        for (int kz = (int)t; kz < M2; kz += (int)nth) {
+          lct_invpsf_slice(h, kz, buf.data(), nullptr);
+          for (size_t i = 0; i < sl; ++i) {
+            invpsf_re[(size_t)kz * sl + i] = (float)buf[i].real();
+            invpsf_im[(size_t)kz * sl + i] = (float)buf[i].imag();
+          }
+        }
+      });
+    for (auto& t : th) t.join();
+  }
+  return HP_OK;
+}

@@ -131,6 +131,14 @@ def synthetic_joints(batch: int, hm: int, seed: int = 2, num_joints: int = 24) -
     return lo + (hi - lo) * torch.rand(batch, num_joints, 3, generator=g)
 
 
+def synthetic_joints_box(batch: int, whd, seed: int = 2, num_joints: int = 24) -> torch.Tensor:
+    """(B, J, 3) joint targets (x, y, z) inside the central 3/4 of a heat-map of W x H x D = `whd` voxels (the decode's
+    axis order: x runs along W, z along D); synthetic_joints() is the cubic case."""
+    g = torch.Generator().manual_seed(seed)
+    ext = torch.tensor([float(v) for v in whd])
+    return ext / 8.0 + (ext * 0.75) * torch.rand(batch, num_joints, 3, generator=g)
+
+
 def mpjpe(pred: torch.Tensor, ref: torch.Tensor, num_joints: int = 24) -> float:
     """Mean per-joint position error in heat-map voxels between two (B,3J) decodes
     (definition: SURVEY.md 8d; x31.25 gives mm for the 2 m wall / 64 voxels)."""

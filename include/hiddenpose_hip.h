@@ -169,6 +169,11 @@ int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void* dy, const 
                                    const void* addend, const unsigned char* addend_mask, void* stream);
 /* dw_packed (same layout as w_fwd) is zeroed and accumulated by the call. */
 int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, const void* dy, float* dw_packed, void* stream);
+/* How hp_conv3d_backward_weight splits its reduction over M = B * output voxels for this descriptor: `msplit` chunks of
+ * `chunk_rows` consecutive rows (the last one shorter) whose partial sums meet in fp32 atomics.  A query for tests that
+ * aim samples at the chunk seams (tests/test_conv_headline_gpu.py); the dedicated stem / dense-1^3 kernels split
+ * differently and ignore it. */
+int hp_conv3d_backward_weight_split(const hp_conv_desc* d, long* msplit, long* chunk_rows);
 
 /* BatchNorm3d (posenet3d_50.py:70-95,133,182) on [M][C] channels-last matrices.  The raw convolution output z, the
  * statistics and every parameter are fp32; `io` says which ACTIVATION tensors of a call are bf16 (0: all fp32): */

@@ -3,8 +3,8 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: lctwin ingest sformer schema consts consts_hr lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train e2e128train_smooth highres
-(default: all; highres needs ~45 GB of RAM and ~15 minutes)
+Sections: lctwin ingest sformer schema consts consts_hr lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train e2e128train_smooth highres e2e512train
+(default: all; highres needs ~45 GB of RAM and ~15 minutes, e2e512train ~55 GB and ~15 minutes)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
 its filler keyed by state_dict name, so tests rebuild identical inputs and
@@ -452,6 +452,76 @@ def sec_e2e128train(smooth=False):
     save("e2e_T128_N128_train_smooth.npz" if smooth else "e2e_T128_N128_train.npz", **out)
 
 
+def sec_e2e512train():
+    """The reference's train step at the BENCHMARK cube (128 x 128 x 512, BASELINE configs[1]'s shape), batch 2, smooth
+    filler -> e2e_T512_N128_train_smooth.npz: losses, joints, sampled heat-maps / refined volume, the 15 named gradients.
+    The step's saved activations need ~80 GB as the reference runs it; this container has 64, so the stem
+    (conv1 -> bn1 -> relu -> maxpool) and every Bottleneck of layer1 / layer2 run under torch.utils.checkpoint
+    (non-reentrant): the SAME reference modules are called, their forward is simply recomputed inside backward instead of
+    being kept.  Train-mode BatchNorm recomputes identical batch statistics, so outputs and gradients are those of the
+    plain step; only the running statistics receive a second momentum update and are therefore NOT stored.  float32
+    only (a float64 twin does not fit), so gradients carry the bars measured against float64 at 128^3."""
+    import resource
+
+    from torch.utils.checkpoint import checkpoint
+
+    from models.NlosPose import NlosPose
+    from utils.criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
+
+    T, N, B = 512, 128, 2
+    cfg = ref_shims.make_cfg(T, N, BIN_LEN[(T, N)])
+    model = NlosPose(cfg)
+    hpt.fill_module(model, smooth=True)
+    named = dict(model.named_parameters())
+    model.train()          # before the stem modules leave the module tree below
+    pn = model.pose_net
+
+    class _Ckpt(torch.nn.Module):
+        def __init__(self, fn):
+            super().__init__()
+            self.fn = fn
+
+        def forward(self, x):
+            return checkpoint(self.fn, x, use_reentrant=False)
+
+    conv1, bn1, relu, pool = pn.conv1, pn.bn1, pn.relu, pn.maxpool
+    pn.conv1 = _Ckpt(lambda x: pool(relu(bn1(conv1(x)))))
+    pn.bn1 = pn.relu = pn.maxpool = torch.nn.Identity()
+    for layer in (pn.layer1, pn.layer2):
+        for i in range(len(layer)):
+            layer[i] = _Ckpt(layer[i])
+
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410)
+    vol = hpt.synthetic_vol(B, T, N)
+    joints = hpt.synthetic_joints_box(B, (N // 2, N // 2, T // 2)).reshape(B, -1)
+    assert bn1.training and pn.layer1[0].fn.bn1.training
+    t0 = time.time()
+    heat, refine = model(meas)
+    print(f"  e2e512train: fwd {time.time()-t0:.1f}s  maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss/2**20:.1f} GiB", flush=True)
+    jl = L2JointLocationLoss(output_3d=True)(heat, joints, torch.ones_like(joints))
+    vl = BCEDiceLoss()(refine.reshape(B, -1), vol.reshape(B, -1))
+    loss = jl + vl
+    loss.backward()
+    print(f"  e2e512train: fwd+bwd {time.time()-t0:.1f}s  joint loss {jl.item():.6g}  voxel loss {vl.item():.6g}  "
+          f"maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss/2**20:.1f} GiB", flush=True)
+    hd = heat.detach()
+    out = {"joint_loss": np.float64(jl.item()), "voxel_loss": np.float64(vl.item()),
+           "joints": softmax_integral_tensor(hd, 24, True, N // 2, N // 2, T // 2).numpy(),
+           "heat_l2_per_joint": hd.reshape(B, 24, -1).double().norm(dim=2).numpy(),
+           "heat_sub": hd[:, :, ::8, ::8, ::8].numpy(), "refine_sub": refine.detach()[:, :, ::8, ::8, ::8].numpy(),
+           "refine_l2": np.float64(refine.detach().double().norm().item())}
+    for k in E2E128_PARAMS:
+        g = named[k].grad.numpy()
+        out["gl2_" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if g.size > 8192:
+            idx = sample_idx(g.size, 4096, 17)
+            out["gidx_" + k] = idx
+            out["gs_" + k] = g.reshape(-1)[idx]
+        else:
+            out["g_" + k] = g.copy()
+    save("e2e_T512_N128_train_smooth.npz", **out)
+
+
 def _lean_lct(T, N, bin_len):
     """Memory-lean restatement of LCT.forward / its adjoint for sizes where the reference's own constructor does not
     fit this container (its (2N,2N,2M) meshgrids + complex128 spectrum need > 60 GB at 1024 x 256 x 256): the PSF comes
@@ -737,7 +807,8 @@ def sec_ingest():
 
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
-            "specular": sec_specular, "bp": sec_bp, "consts_hr": sec_consts_hr, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "e2e128train_smooth": lambda: sec_e2e128train(True), "highres": sec_highres}
+            "specular": sec_specular, "bp": sec_bp, "consts_hr": sec_consts_hr, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "e2e128train_smooth": lambda: sec_e2e128train(True), "highres": sec_highres,
+            "e2e512train": sec_e2e512train}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

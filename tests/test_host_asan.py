@@ -1,0 +1,145 @@
+"""SURVEY section 5's safety net for the host code (CPU only, no device): the HIP-free translation units of the library --
+hp_error.cpp, lct_host.cpp (the LCT constant builder) and rgbe_host.cpp (the Radiance container parser, which reads
+UNTRUSTED file bytes) -- are compiled by the host compiler with -fsanitize=address,undefined
+(`python -m hiddenpose_amd.build --asan-host`) and exercised in a child process with the sanitizer runtime preloaded:
+the host-ABI checks of tests/test_abi_host.py, the decoder tests of tests/test_ingest.py, and a fuzz loop of truncated,
+bit-flipped and header-garbled files.  Any out-of-bounds access, overflow or misaligned / undefined operation aborts the
+child; the test reads its exit status and report."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["HP_ROOT"]); sys.path.insert(0, os.path.join(os.environ["HP_ROOT"], "tests"))
+from hiddenpose_amd import testing as hpt
+from oracle import ingest_oracle as io
+L = C.CDLL(os.environ["HP_ASAN_LIB"])
+L.hp_last_error_string.restype = C.c_char_p
+L.hp_lct_host_constants.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 6
+L.hp_rgbe_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+assert L.hp_version() >= 100
+
+# ---- LCT host constants against the reference goldens (tests/test_abi_host.py, same assertions)
+g = np.load(os.path.join(os.environ["HP_ROOT"], "tests", "golden", "lct_consts.npz"))
+for T, N, bin_len, full in ((32, 16, 0.16, True), (128, 128, 0.04, False)):
+    tag = f"T{T}_N{N}"
+    gridz = np.zeros(T, np.float32); mtx = np.zeros((T, T), np.float32); z = np.zeros((2 * N, 2 * N), np.int32); cnt = np.zeros(1, np.int64)
+    re_ = np.zeros((2 * T, 2 * N, 2 * N), np.float32) if full else None
+    im_ = np.zeros_like(re_) if full else None
+    rc = L.hp_lct_host_constants(T, N, bin_len, 2.0, gridz.ctypes.data, mtx.ctypes.data, z.ctypes.data, cnt.ctypes.data,
+                                 re_.ctypes.data if full else None, im_.ctypes.data if full else None)
+    assert rc == 0, L.hp_last_error_string()
+    assert np.array_equal(gridz, g[tag + "_gridz"])
+    r, c = np.nonzero(mtx)
+    assert np.array_equal(r, g[tag + "_mtx_rows"]) and np.array_equal(c, g[tag + "_mtx_cols"]) and np.array_equal(mtx[r, c], g[tag + "_mtx_vals"])
+    assert int(cnt[0]) == int(g[tag + "_psf_nnz"]) and np.array_equal(z.astype(np.int16), g[tag + "_psf_zidx"])
+    if full:
+        assert np.abs(re_ - g[tag + "_invpsf_re"]).max() < 1e-6 and np.abs(im_ - g[tag + "_invpsf_im"]).max() < 1e-6
+T = 512
+mtx = np.zeros((T, T), np.float32)
+assert L.hp_lct_host_constants(T, 1, 0.01, 2.0, None, mtx.ctypes.data, None, None, None, None) == 0
+r, c = np.nonzero(mtx)
+assert np.array_equal(r, g["T512_N128_mtx_rows"]) and np.array_equal(mtx[r, c], g["T512_N128_mtx_vals"])
+assert L.hp_lct_host_constants(100, 16, 0.1, 2.0, None, None, None, None, None, None) == -1
+assert b"power of two" in L.hp_last_error_string()
+print("lct host constants: ok")
+
+# ---- Radiance container decoder
+def decode(data, cap_limit=1 << 26):
+    buf = (C.c_ubyte * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    w, h = C.c_int(0), C.c_int(0)
+    rc = L.hp_rgbe_decode(buf, len(data), C.byref(w), C.byref(h), None, 0)
+    if rc != 0:
+        return rc, None
+    need = w.value * h.value * 4
+    assert 0 < need <= 64 * len(data) + 256, (w.value, h.value, len(data))   # the size query never asks for an absurd buffer
+    if need > cap_limit:
+        return 1, None
+    out = np.zeros(need, np.uint8)
+    rc = L.hp_rgbe_decode(buf, len(data), C.byref(w), C.byref(h), out.ctypes.data, need)
+    return rc, out.reshape(h.value, w.value, 4)
+
+files = []
+for rle in (True, False):
+    for (fr, H, W, seed) in ((40, 8, 24, 11), (4, 8, 16, 1), (3, 5, 40, 2)):
+        rgbe = hpt.synthetic_rgbe(fr, H, W, seed=seed)
+        data = io.rgbe_write(rgbe, rle=rle)
+        rc, got = decode(data)
+        assert rc == 0 and np.array_equal(got, rgbe), (rle, fr, H, W)
+        files.append(data)
+rc, _ = decode(b"P6\n1 1\n255\n\0\0\0")
+assert rc == -1 and b"signature" in L.hp_last_error_string()
+rc, _ = decode(files[1][:-7])
+assert rc < 0
+# a too-small output buffer is refused, not overrun
+data = files[0]
+buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+w, h = C.c_int(0), C.c_int(0)
+small = np.zeros(16, np.uint8)
+assert L.hp_rgbe_decode(buf, len(data), C.byref(w), C.byref(h), small.ctypes.data, 16) == -1
+print("rgbe decoder: ok")
+
+# ---- fuzz: truncated / bit-flipped / header-garbled files must end in a status code
+rng = np.random.Generator(np.random.PCG64(2024))
+n_ok = n_err = 0
+cases = 0
+for data in files:
+    hdr_end = data.index(b"\n\n") + 2
+    for k in range(60):
+        kind = k % 6
+        b = bytearray(data)
+        if kind == 0:                                  # truncation anywhere (header included)
+            b = b[:int(rng.integers(0, len(b)))]
+        elif kind == 1:                                # byte flips in the pixel data
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(hdr_end, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 2:                                # byte flips anywhere
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 3:                                # the resolution line replaced by extreme / malformed numbers
+            res_end = b.index(b"\n", hdr_end)
+            choice = [b"-Y 2147483647 +X 2147483647", b"-Y 99999999999999999999 +X 7", b"-Y 1 +X 2000000000", b"-Y 0 +X 0",
+                      b"-Y -5 +X 3", b"+X 8 -Y 8", b"-Y 8 +X", b"-Y 40000 +X 40000", b"-Y 8 +X 32768", b""][int(rng.integers(0, 10))]
+            b = b[:hdr_end] + choice + b[res_end:]
+        elif kind == 4:                                # run lengths that overshoot the scanline
+            for i in range(hdr_end + 30, len(b), max(7, len(b) // 23)):
+                b[i] = 255
+        else:                                          # a valid header followed by noise
+            res_end = b.index(b"\n", hdr_end) + 1
+            b = b[:res_end] + bytes(rng.integers(0, 256, int(rng.integers(0, 4096)), dtype=np.uint8))
+        rc, _ = decode(bytes(b))
+        cases += 1
+        if rc == 0: n_ok += 1
+        else: n_err += 1
+assert cases >= 200
+print(f"fuzz: {cases} cases, {n_ok} decoded, {n_err} refused with a status code")
+print("ASAN-CHILD-OK")
+'''
+
+
+def test_host_only_sources_under_asan_ubsan(tmp_path):
+    from hiddenpose_amd import build as hb
+
+    try:
+        lib = hb.build_asan_host()
+    except (RuntimeError, FileNotFoundError) as e:   # no host compiler / sanitizer runtime on this box
+        pytest.skip(f"host sanitizer build unavailable: {str(e)[:200]}")
+    rt = hb.sanitizer_runtime()
+    if not rt:
+        pytest.skip("libasan / libubsan not found")
+    env = dict(os.environ, LD_PRELOAD=rt, HP_ASAN_LIB=lib, HP_ROOT=ROOT,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97:allocator_may_return_null=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98")
+    script = tmp_path / "asan_child.py"
+    script.write_text(CHILD)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    report = (r.stdout + "\n" + r.stderr)[-6000:]
+    assert r.returncode == 0 and "ASAN-CHILD-OK" in r.stdout, f"child exit {r.returncode}\n{report}"
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, report
+    print(r.stdout)

@@ -103,6 +103,36 @@ def test_hip_bf16_attention_config5_shape_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_hip_config5_as_benchmarked_batch2_bf16_linears_fp16_attention_vs_oracle():
+    """BASELINE configs[4] in the arithmetic bench.py times it in (bf16 matrix-core Linear layers AND fp16 MFMA patch
+    attention together), at the config-5 geometry with a batch > 1 (the bench runs batch 8; batch 2 exercises the same batch
+    strides and keeps the float32 oracle to ~10 s): every sample against the oracle's output for THAT sample.  Operand
+    rounding 2^-9 per Linear through 8 layers of pre-norm residual blocks: measured ~1e-2; a batch-stride slip (sample 1
+    computed from sample 0's tokens, or written over it) shows as O(1)."""
+    kw = dict(dim=256, num_frames=16, num_joints=24, image_size=128, patch_size=4, channels=1, depth=8, heads=8,
+              dim_head=32, out_dim=512)
+    m = NlosPoseSformer(**kw)
+    hpt.fill_module(m, "sformer.")
+    video = torch.rand(2, 16, 1, 128, 128, generator=torch.Generator().manual_seed(55))
+    sd = {"sformer." + k: v for k, v in m.state_dict().items()}
+    ref = O.nlospose_sformer(video, sd, patch_size=4, heads=8)
+    m = m.cuda()
+    m.linear_precision = "bf16"
+    m.attention_precision = "fp16"
+    y = m(video.cuda())
+    assert y.shape == ref.shape == (2, 24, 4, 128)
+    e = [rel_l2(y[b], ref[b]) for b in range(2)]
+    cross = rel_l2(y[1], ref[0])
+    print(f"config 5 as benchmarked (bf16 Linear + fp16 attention), batch 2: rel-L2 per sample {e[0]:.2e} {e[1]:.2e}; "
+          f"sample 1 against sample 0's reference {cross:.2e}")
+    assert max(e) < 3e-2
+    assert rel_l2(ref[1], ref[0]) > 10 * max(e) and cross > 10 * max(e)   # the two samples differ by far more than the error bar
+    # and the order of the batch does not matter: sample 1 alone equals sample 1 of the pair
+    y1 = m(video[1:].cuda())
+    assert rel_l2(y1[0], y[1]) < 1e-5
+
+
+@pytest.mark.gpu
 def test_16bit_patch_attention_op_vs_float64():
     """hp_sformer_attention alone on random Q, K, V at the config-5 token layout (batch 1): the fp32 kernel against a float64
     evaluation of models/NlosPoseSformer.py:284-319 (patch queries attend to [24 joint tokens | their frame]), and the two
