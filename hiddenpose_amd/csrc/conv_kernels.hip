@@ -60,6 +60,7 @@ struct IgemmGeom {
   int geglu;               // 1: GEGLU epilogue (hp_linear_geglu_forward): columns [0, 64) of every 128-column tile are values, [64, 128)
                            //    their gates; Y has Nout / 2 columns and receives value * gelu(gate)
   int slab;                // > 0: M tiles per XCD -- XCD k (workgroup b runs on XCD b % 8) walks M tiles k * slab .. (k + 1) * slab - 1
+  long welems;             // elements of the packed weight image this geometry reads (descriptor extents)
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -338,8 +339,10 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i) wvoff[i] = wvalid[i] ? (unsigned)(wrow[i] * 4) : OOB;
   }
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + (rowbase + min_xoff)), 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, OOB, 0x00020000);
+  // num_records = what is left of the tensor from the descriptor's base (hp_extent): offsets made of OOB stay out of range
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(X + (rowbase + min_xoff)), 0, hp_extent((long)g.B * g.Di * g.Hi * g.Wi * g.Cin, rowbase + min_xoff, 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, hp_extent(g.welems, 0, 4), 0x00020000);
   float4 ra[4], rbw[BN / 32];
   uint4 ra8[XH ? 4 : 1];        // XH: 8 bf16 per row as loaded
   float4 rbw2[XH ? BN / 32 : 1];  // XH: second half of the 8 weights per row (fp32 weights)
@@ -667,11 +670,14 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     // instruction in matrix-pipe time; the K = 64 layers spent ~15 % of their time in this epilogue).
     const bool fast = !IOH && dense_out && vec_ok && m0 + BM <= g.M && n0 + BN <= g.Nout && !g.geglu;
     const long tile_el = m0 * g.Nout + n0;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)Y + tile_el), 0, 0x80000000u, 0x00020000);
+    // (used by the `fast` whole-tile path only: fp32 tensors of M x Nout elements; extents: hp_extent)
+    const long y_el = g.M * g.Nout;
+    const unsigned y_rec = hp_extent(y_el, tile_el, 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)Y + tile_el), 0, y_rec, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((addend ? (const float*)addend : (const float*)Y) + tile_el), 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mrs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((amask ? amask : (const unsigned char*)Y) + (tile_el >> 2)), 0, 0x80000000u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)((addend ? (const float*)addend : (const float*)Y) + tile_el), 0, y_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((amask ? amask : (const unsigned char*)Y) + (tile_el >> 2)), 0, hp_extent(y_el >> 2, tile_el >> 2, 1), 0x00020000);
     constexpr int RPK = CT / Q;  // staging rows per round of 256 threads
     const int r_l = tid / Q, q_l = tid % Q;
     const unsigned vo = (unsigned)((r_l * g.Nout + 4 * q_l) * 4);
@@ -1278,8 +1284,10 @@ __global__ __launch_bounds__(CT) void k_wgrad_bl(const float* __restrict__ X, co
     tmin = (t == 0 || o < tmin) ? o : tmin;
   }
   const long xrow0 = ((long)(zb0 * g.s) * g.Hi + y0 * g.s) * g.Wi + x0 * g.s + tmin;
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dY + orow0 * g.Nout + n0), 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xrow0 * g.Cin + c0), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(dY + orow0 * g.Nout + n0), 0, hp_extent((long)g.B * g.Do * g.Ho * g.Wo * g.Nout, orow0 * g.Nout + n0, (int)sizeof(*dY)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(X + xrow0 * g.Cin + c0), 0, hp_extent((long)g.B * g.Di * g.Hi * g.Wi * g.Cin, xrow0 * g.Cin + c0, (int)sizeof(*X)), 0x00020000);
   // per-axis strides of the two row indices, in rows (scalars)
   const int oy_s = g.os * g.Wo, oz_s = g.os * g.Ho * g.Wo;            // dY row  = zb * oz_s + y * oy_s + x * os + const
   const int xy_s = g.s * g.Wi, xz_s = g.s * g.Hi * g.Wi;              // X row   = zb * xz_s + y * xy_s + x * s  + tap + const
@@ -1469,8 +1477,10 @@ __global__ __launch_bounds__(CT) void k_wgrad_blh(const unsigned short* __restri
     tmin = (t == 0 || o < tmin) ? o : tmin;
   }
   const long xrow0 = ((long)(zb0 * g.s) * g.Hi + y0 * g.s) * g.Wi + x0 * g.s + tmin;
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(dY + orow0 * g.Nout + n0), 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(X + xrow0 * g.Cin + c0), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(dY + orow0 * g.Nout + n0), 0, hp_extent((long)g.B * g.Do * g.Ho * g.Wo * g.Nout, orow0 * g.Nout + n0, (int)sizeof(*dY)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(X + xrow0 * g.Cin + c0), 0, hp_extent((long)g.B * g.Di * g.Hi * g.Wi * g.Cin, xrow0 * g.Cin + c0, (int)sizeof(*X)), 0x00020000);
   const int oy_s = g.os * g.Wo, oz_s = g.os * g.Ho * g.Wo, xy_s = g.s * g.Wi, xz_s = g.s * g.Hi * g.Wi;
   const int ybytes = g.Nout * 2, xbytes = g.Cin * 2;
   int toff[NTAP];
@@ -1725,7 +1735,9 @@ __global__ __launch_bounds__(CT, 3) void k_stem_dgrad(const float* __restrict__ 
   float4 areg[8];
   auto fetch_a = [&](int bz) {
     const float* base = dZ + ((((long)b * D + bz * SP_Z) * H + y0) * W + x0) * 64;
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bz * SP_Z + wave < D ? 0x80000000u : 0u, 0x00020000);
+    const long base_el = ((((long)b * D + bz * SP_Z) * H + y0) * W + x0) * 64;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)base, 0, bz * SP_Z + wave < D ? hp_extent((long)gridDim.y * D * H * W * 64, base_el, 4) : 0u, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 8; ++j) areg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + 16u * j, 0, 0));
   };
@@ -2670,6 +2682,8 @@ static int make_plan(const hp_conv_desc& d, ConvPlan& p) {
   set_shifts(p.fwd);
   set_shifts(p.dgrad);
   set_shifts(p.wgrad);
+  p.fwd.welems = p.wgrad.welems = p.stem ? (long)d.Cout * ((343 + 31) / 32 * 32) : (long)d.Cout * d.Cin * k * k * k;
+  p.dgrad.welems = (long)d.Cout * d.Cin * k * k * k;
   return HP_OK;
 }
 

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   constexpr int SK = (WG_PLANE + 255) / 256;
   // buffer loads (see k_dconv3_mfma): fixed per-thread byte offsets, out-of-range = the zero padding, plane in the scalar offset
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+  // num_records: the rest of sample b's channels from this group on (hp_extent) -- a slip stays inside the sample's tensor
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, hp_extent((long)(cin - cig * 4) * cs, 0, 4), 0x00020000);
   unsigned soff[SK];
 #pragma unroll
   for (int k = 0; k < SK; ++k) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma(const float* __res
   const int lbase = (sub * WG_PY + 2 * wave) * WG_PX + blk;
   // g of one plane: 8 (row, run) values per lane
   // g through a buffer descriptor at this workgroup's 4 output channels: lane part (channel sub, x run) fixed, row and plane scalar
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, hp_extent((long)(cout - cog * 4) * cs, 0, 4), 0x00020000);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   unsigned goff[4];
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __res
   const float* xb = x + ((long)b * cin + cig * 4) * cs;
   const bool want_db = cig == 0;
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, hp_extent((long)(cin - cig * 4) * cs, 0, 4), 0x00020000);
   // staging item it = tid + 256 k: (channel c, row ly, group gq) -> cells lx = 4 gq .. 4 gq + 3 of that row, packed into one
   // 8-byte LDS write; every cell has its own fixed offset (out of range = zero padding / past the volume / past cin)
   constexpr int SKI = (WH_ITEMS + 255) / 256;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_bf16(const float* __res
   __syncthreads();
   // this lane's window inside a slot for row r: halves (sub * PY + 2 * wave + r + dy) * ROW + 4 * blk .. + 7
   const int lbase = (sub * WG_PY + 2 * wave) * WH_ROW + 4 * blk;
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, hp_extent((long)(cout - cog * 4) * cs, 0, 4), 0x00020000);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int xv = x0 + 4 * blk;
   const unsigned goff = (co_ok && xv < W) ? (unsigned)(((long)sub * cs + xv) * 4) : OOB;   // W % 4 == 0: the four voxels are in or out together
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
 
   constexpr int SK = (W1_PLANE + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;   // buffer loads as in k_dconv3_wgrad_mfma
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, hp_extent(cs, 0, 4), 0x00020000);
   unsigned soff[SK];
 #pragma unroll
   for (int k = 0; k < SK; ++k) {
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_wgrad_mfma_c1(const float* __
   __syncthreads();
   const int lbase = (2 * wave) * WG_PX + blk;
   // g through a buffer descriptor at this workgroup's 4 output channels: lane part (channel sub, x run) fixed, row and plane scalar
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(g + ((long)b * cout + cog * 4) * cs), 0, hp_extent((long)(cout - cog * 4) * cs, 0, 4), 0x00020000);
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   unsigned goff[4];
 #pragma unroll
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     // conditions inside the main loop the compiler merged the rotating register sets with v_mov copies at the joins, and a
     // copy (or a zero-fill) of a register whose load is still in flight needs s_waitcnt vmcnt(0) -- the prefetch was waited
     // for at the top of every step, whatever the number of sets (seen in the ISA; round 3).
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, hp_extent((long)(cin - c0) * ics, 0, 4), 0x00020000);
     auto stage_load_fast = [&](int zin, float (&v)[SK]) {   // plane known to lie inside the volume (or clamped into it)
       const int zz = PADMODE == 1 ? min(max(zin, 0), Di - 1) : zin;
       const unsigned zs = (unsigned)((long)zz * Hi * Wi * 4);
@@ -872,8 +873,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_mfma(const float* __restrict_
     auto out_off = [&](int z, int r, int i) { return (unsigned)(((long)i * ocs + ((long)z * Ho + (y0 + 2 * wv + r)) * Wo) * 4); };
     // steady-state form: no step / row conditions beyond the loop-invariant ones, and NO write to ev on the paths that do not
     // load (a v_mov into a register some other path loads into costs an s_waitcnt vmcnt(0) at the join)
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
+    const unsigned y_rec = hp_extent((long)(cout - cog * 4) * ocs, 0, 4);   // the rest of sample b's output channels
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, y_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, y_rec, 0x00020000);
     auto epi_load_fast = [&](int z, EpiVals& ev) {
       if (need_a) {
 #pragma unroll
@@ -1127,7 +1129,8 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
     // steady-state form: plane inside the volume; a channel past cin re-reads the sweep's last channel (its weights are zero)
     __amdgpu_buffer_rsrc_t xrs[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) xrs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)xq[q], 0, OOB, 0x00020000);
+    for (int q = 0; q < NQ; ++q)
+      xrs[q] = __builtin_amdgcn_make_buffer_rsrc((void*)xq[q], 0, hp_extent((long)(cin - min(c0 + 4 * q, cin - 1)) * ics, 0, 4), 0x00020000);
     auto stage_load_fast = [&](int zin, float (&v)[SKC][4 * NQ]) {
       const int zz = PADMODE == 1 ? min(max(zin, 0), Di - 1) : zin;
       const unsigned zp = (unsigned)((long)zz * Hi * Wi * 4);
@@ -1191,8 +1194,9 @@ __global__ __launch_bounds__(256, 2) void k_dconv3_bf16(const float* __restrict_
     auto out_off = [&](int z, int r, int i) { return (unsigned)(((long)i * ocs + ((long)z * Ho + (y0 + 2 * wv + r)) * Wo) * 4); };
     // steady-state form: no step / row conditions beyond the loop-invariant ones, and NO write to ev on the paths that do not
     // load (a v_mov into a register some other path loads into costs an s_waitcnt vmcnt(0) at the join)
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, 0x80000000u, 0x00020000);
+    const unsigned y_rec = hp_extent((long)(cout - cog * 4) * ocs, 0, 4);   // the rest of sample b's output channels
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(y + ybase), 0, y_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)((res ? res : y) + ybase), 0, y_rec, 0x00020000);
     auto epi_load_fast = [&](int z, EpiVals& ev) {
       if (need_a) {
 #pragma unroll
@@ -1763,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x,
     const int ro0 = __builtin_amdgcn_readfirstlane(roff[0]), ro1 = __builtin_amdgcn_readfirstlane(roff[1]),
               ro2 = __builtin_amdgcn_readfirstlane(roff[2]);   // a wave is one row: scalar
     auto request = [&](int zin, bool zok, float (&v)[3][6]) {   // zok: scalar
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, zok ? OOB : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, zok ? hp_extent((long)Di * plane_elems, 0, 4) : 0u, 0x00020000);
       const long zp = (long)min(max(zin, 0), Di - 1) * plane_elems;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -1774,7 +1778,7 @@ __global__ __launch_bounds__(256) void k_stencil_c1(const float* __restrict__ x,
         v[r][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_r, so, 0));
       }
     };
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, hp_extent((long)Di * plane_elems, 0, 4), 0x00020000);
     auto request_fast = [&](int zin, float (&v)[3][6]) {   // plane inside the volume (PADMODE 1: clamped into it)
       const long zp = (long)(PADMODE == 1 ? min(max(zin, 0), Di - 1) : zin) * plane_elems;
 #pragma unroll
@@ -1890,15 +1894,19 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
   xcd_slab_init();
   // the kernels address a 4-channel group of planes through one buffer descriptor (31-bit byte offsets: beyond it loads read
   // zero and stores are dropped)
-  HP_REQUIRE((long)Di * Hi * Wi * 16 < (1l << 31) && (long)Do * Ho * Wo * 16 < (1l << 31),
-             "thin-channel convolution: a volume of more than 2^27 voxels per channel is not supported (%d x %d x %d)", Di, Hi, Wi);
+  // (the single-channel stencil addresses ONE plane set per sample: 4 bytes per voxel inside its descriptor, 2^29 voxels)
+  const bool stencil = cin == 1 && cout == 1 && !stats && !use_mfma_c1();
+  const long vox_bytes = stencil ? 4 : 16;
+  HP_REQUIRE((long)Di * Hi * Wi * vox_bytes < (1l << 31) && (long)Do * Ho * Wo * vox_bytes < (1l << 31),
+             "thin-channel convolution: a volume of more than 2^%d voxels per channel is not supported (%d x %d x %d)", stencil ? 29 : 27, Di,
+             Hi, Wi);
   const int tiles_x = (Wo + WG_TX - 1) / WG_TX, tiles_y = (Ho + WG_TY - 1) / WG_TY, cog_n = (cout + 3) / 4;
   const long cols = (long)tiles_x * tiles_y * B * cog_n;
   int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (1536 + cols - 1) / cols));
   const int zchunk = (Do + zsplit - 1) / zsplit;
   zsplit = (Do + zchunk - 1) / zchunk;
   dim3 grid((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)B, (unsigned)cog_n);
-  if (cin == 1 && cout == 1 && !stats && !use_mfma_c1()) {
+  if (stencil) {
     static const int zc_env = getenv("HP_STENCIL_ZC") ? atoi(getenv("HP_STENCIL_ZC")) : 0;
     const int zc = zc_env > 0 ? zc_env : (Do >= 256 ? 64 : std::max(8, (Do + 3) / 4));
     dim3 g1((unsigned)((Wo + 255) / 256), (unsigned)((Ho + 3) / 4), (unsigned)(B * ((Do + zc - 1) / zc)));
@@ -2027,9 +2035,11 @@ extern "C" int hp_dconv3_backward_data_p(const float* gy, const float* w, float*
     HP_PROF("dconv3_dgrad", st);
     return run_dconv(gy, w, nullptr, nullptr, gx, nullptr, 1.0f, B, cout, cin, D, H, W, D, H, W, 1, 27, (long)cin * 27, 1, 0, st, precision);
   }
-  HP_REQUIRE((long)D * H * W * 16 < (1l << 31),
-             "thin-channel data gradient: a volume of more than 2^27 voxels per channel is not supported (%d x %d x %d)", D, H, W);
-  if (cin == 1 && cout == 1 && !use_mfma_c1()) {
+  const bool stencil = cin == 1 && cout == 1 && !use_mfma_c1();
+  HP_REQUIRE((long)D * H * W * (stencil ? 4 : 16) < (1l << 31),
+             "thin-channel data gradient: a volume of more than 2^%d voxels per channel is not supported (%d x %d x %d)", stencil ? 29 : 27, D,
+             H, W);
+  if (stencil) {
     // single-channel layers (FeatureExtraction): the replicate fold inside the stencil kernel, one pass over (D, H, W)
     HP_PROF("dconv3_dgrad", st);
     static const int zc_env = getenv("HP_STENCIL_ZC") ? atoi(getenv("HP_STENCIL_ZC")) : 0;

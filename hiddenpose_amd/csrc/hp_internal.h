@@ -60,6 +60,17 @@ __device__ __forceinline__ void hp_st4(void* p, long i, float4 v, int half) {
   }
   *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = v;
 }
+// num_records of a raw buffer descriptor whose base lies `base_off` elements into a tensor of `total` elements of `esz`
+// bytes: the tensor's TRUE remaining extent, so that an addressing slip reads zeros / drops the store instead of touching
+// whatever is allocated next to the tensor (round 3's descriptors all said 2^31: the range check was the sign bit only).
+// Capped at 2^31: offsets with bit 31 set stay out of range (the "force this lane out of range" idiom of the tile loads),
+// and tensors whose remainder genuinely exceeds 2 GiB (layer 1 and the stem at the headline shape) keep that cap.
+// A base below the tensor (negative base_off: tiles whose first taps reach outside the volume, masked per lane) only
+// lengthens the extent; the low end is guarded by those masks, not by the descriptor.
+__device__ __forceinline__ unsigned hp_extent(long total, long base_off, int esz) {
+  const long bytes = (total - base_off) * esz;
+  return bytes >= 0x80000000l ? 0x80000000u : bytes > 0 ? (unsigned)bytes : 0u;
+}
 __device__ __forceinline__ void hp_st1(void* p, long i, float v, int half) {
   if (half) reinterpret_cast<unsigned short*>(p)[i] = hp_f2bf(v);
   else reinterpret_cast<float*>(p)[i] = v;

@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: lctwin ingest sformer schema consts consts_hr lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train e2e128train_smooth highres e2e512train
+Sections: lctwin ingest sformer schema consts consts_hr lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train e2e128train_smooth highres e2e512train e2e512train_b1
 (default: all; highres needs ~45 GB of RAM and ~15 minutes, e2e512train ~55 GB and ~15 minutes)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
@@ -452,29 +452,12 @@ def sec_e2e128train(smooth=False):
     save("e2e_T128_N128_train_smooth.npz" if smooth else "e2e_T128_N128_train.npz", **out)
 
 
-def sec_e2e512train():
-    """The reference's train step at the BENCHMARK cube (128 x 128 x 512, BASELINE configs[1]'s shape), batch 2, smooth
-    filler -> e2e_T512_N128_train_smooth.npz: losses, joints, sampled heat-maps / refined volume, the 15 named gradients.
-    The step's saved activations need ~80 GB as the reference runs it; this container has 64, so the stem
-    (conv1 -> bn1 -> relu -> maxpool) and every Bottleneck of layer1 / layer2 run under torch.utils.checkpoint
-    (non-reentrant): the SAME reference modules are called, their forward is simply recomputed inside backward instead of
-    being kept.  Train-mode BatchNorm recomputes identical batch statistics, so outputs and gradients are those of the
-    plain step; only the running statistics receive a second momentum update and are therefore NOT stored.  float32
-    only (a float64 twin does not fit), so gradients carry the bars measured against float64 at 128^3."""
-    import resource
-
+def _ckpt_wrap(model):
+    """Stem (conv1 -> bn1 -> relu -> maxpool) and every Bottleneck of layer1 / layer2 of the reference's posenet under
+    torch.utils.checkpoint (non-reentrant): the SAME reference modules are called; their forward is recomputed inside
+    backward instead of being kept.  Train-mode BatchNorm recomputes identical batch statistics, so outputs and gradients are
+    those of the plain step; only the running statistics receive a second momentum update (never stored from these runs)."""
     from torch.utils.checkpoint import checkpoint
-
-    from models.NlosPose import NlosPose
-    from utils.criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
-
-    T, N, B = 512, 128, 2
-    cfg = ref_shims.make_cfg(T, N, BIN_LEN[(T, N)])
-    model = NlosPose(cfg)
-    hpt.fill_module(model, smooth=True)
-    named = dict(model.named_parameters())
-    model.train()          # before the stem modules leave the module tree below
-    pn = model.pose_net
 
     class _Ckpt(torch.nn.Module):
         def __init__(self, fn):
@@ -484,25 +467,44 @@ def sec_e2e512train():
         def forward(self, x):
             return checkpoint(self.fn, x, use_reentrant=False)
 
+    model.train()          # before the stem modules leave the module tree below
+    pn = model.pose_net
     conv1, bn1, relu, pool = pn.conv1, pn.bn1, pn.relu, pn.maxpool
     pn.conv1 = _Ckpt(lambda x: pool(relu(bn1(conv1(x)))))
     pn.bn1 = pn.relu = pn.maxpool = torch.nn.Identity()
     for layer in (pn.layer1, pn.layer2):
         for i in range(len(layer)):
             layer[i] = _Ckpt(layer[i])
-
-    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410)
-    vol = hpt.synthetic_vol(B, T, N)
-    joints = hpt.synthetic_joints_box(B, (N // 2, N // 2, T // 2)).reshape(B, -1)
     assert bn1.training and pn.layer1[0].fn.bn1.training
+
+
+def _e2e512_step(B, dtype):
+    """One train-mode forward + both losses + backward of the reference at 128 x 128 x 512, smooth filler."""
+    import resource
+
+    from models.NlosPose import NlosPose
+    from utils.criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
+
+    T, N = 512, 128
+    cfg = ref_shims.make_cfg(T, N, BIN_LEN[(T, N)])
+    model = NlosPose(cfg)
+    hpt.fill_module(model, smooth=True)
+    if dtype == torch.float64:
+        model = model.double()
+        lctm = model.feature_propagation.method
+        for a in ("gridz_1xMx1x1_todev", "mtx_MxM_todev", "mtxi_MxM_todev", "invpsf_real_todev", "invpsf_imag_todev", "datapad_Dx2Tx2Hx2W"):
+            setattr(lctm, a, getattr(lctm, a).double())
+    named = dict(model.named_parameters())
+    _ckpt_wrap(model)
+    meas = hpt.synthetic_meas(B, T, N, "transient", seed=410).to(dtype)
+    vol = hpt.synthetic_vol(B, T, N).to(dtype)
+    joints = hpt.synthetic_joints_box(B, (N // 2, N // 2, T // 2)).reshape(B, -1).to(dtype)
     t0 = time.time()
     heat, refine = model(meas)
-    print(f"  e2e512train: fwd {time.time()-t0:.1f}s  maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss/2**20:.1f} GiB", flush=True)
     jl = L2JointLocationLoss(output_3d=True)(heat, joints, torch.ones_like(joints))
     vl = BCEDiceLoss()(refine.reshape(B, -1), vol.reshape(B, -1))
-    loss = jl + vl
-    loss.backward()
-    print(f"  e2e512train: fwd+bwd {time.time()-t0:.1f}s  joint loss {jl.item():.6g}  voxel loss {vl.item():.6g}  "
+    (jl + vl).backward()
+    print(f"  e2e512 step B={B} {dtype}: fwd+bwd {time.time()-t0:.1f}s  joint loss {jl.item():.9g}  voxel loss {vl.item():.9g}  "
           f"maxrss {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss/2**20:.1f} GiB", flush=True)
     hd = heat.detach()
     out = {"joint_loss": np.float64(jl.item()), "voxel_loss": np.float64(vl.item()),
@@ -510,16 +512,54 @@ def sec_e2e512train():
            "heat_l2_per_joint": hd.reshape(B, 24, -1).double().norm(dim=2).numpy(),
            "heat_sub": hd[:, :, ::8, ::8, ::8].numpy(), "refine_sub": refine.detach()[:, :, ::8, ::8, ::8].numpy(),
            "refine_l2": np.float64(refine.detach().double().norm().item())}
-    for k in E2E128_PARAMS:
-        g = named[k].grad.numpy()
-        out["gl2_" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+    grads = {k: named[k].grad.numpy().copy() for k in E2E128_PARAMS}
+    return out, grads
+
+
+def _store_grads(out, grads, prefix_l2, prefix_s, prefix_full):
+    for k, g in grads.items():
+        out[prefix_l2 + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
         if g.size > 8192:
             idx = sample_idx(g.size, 4096, 17)
             out["gidx_" + k] = idx
-            out["gs_" + k] = g.reshape(-1)[idx]
+            out[prefix_s + k] = g.reshape(-1)[idx]
         else:
-            out["g_" + k] = g.copy()
+            out[prefix_full + k] = g.copy()
+
+
+def sec_e2e512train():
+    """The reference's train step at the BENCHMARK cube (128 x 128 x 512, BASELINE configs[1]'s shape), batch 2, smooth
+    filler -> e2e_T512_N128_train_smooth.npz: losses, joints, sampled heat-maps / refined volume, the 15 named gradients.
+    The step's saved activations need ~80 GB as the reference runs it; this container has 64, hence _ckpt_wrap (27 GiB
+    peak).  float32 only: the float64 twin of this batch needs > 51 GB for the stem BatchNorm's backward alone (three
+    17 GB tensors) -- see e2e512train_b1 for the float64 yardstick at this volume."""
+    out, grads = _e2e512_step(2, torch.float32)
+    _store_grads(out, grads, "gl2_", "gs_", "g_")
     save("e2e_T512_N128_train_smooth.npz", **out)
+
+
+def sec_e2e512train_b1():
+    """The same step at batch 1 in float32 AND float64 -> e2e_T512_N128_train_smooth_b1.npz: the float64 gradients are the
+    yardstick at the benchmark volume (train-mode BatchNorm over one sample's voxels is well defined: >= 2048 values per
+    channel at layer4), spread_* = how far the reference's own float32 gradients lie from them."""
+    out, g32 = _e2e512_step(1, torch.float32)
+    _store_grads(out, g32, "gl2_", "gs_", "g_")
+    o64, g64 = _e2e512_step(1, torch.float64)
+    out["loss64"] = np.float64(o64["joint_loss"] + o64["voxel_loss"])
+    out["joint_loss64"], out["voxel_loss64"] = o64["joint_loss"], o64["voxel_loss"]
+    out["joints64"] = o64["joints"]
+    out["heat_sub64"], out["refine_sub64"] = o64["heat_sub"].astype(np.float32), o64["refine_sub"].astype(np.float32)
+    for k in E2E128_PARAMS:
+        a, b = g32[k].astype(np.float64), g64[k]
+        out["spread_" + k] = np.float64(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+        out["g64l2_" + k] = np.float64(np.linalg.norm(b))
+        if ("gidx_" + k) in out:
+            out["gs64_" + k] = b.reshape(-1)[out["gidx_" + k]]
+        else:
+            out["g64_" + k] = b.copy()
+    print("  fp32-vs-fp64 gradient spread of the reference at 512x128x128, B=1: " +
+          ", ".join(f"{k.split('.', 1)[1]} {float(out['spread_' + k]):.1e}" for k in E2E128_PARAMS))
+    save("e2e_T512_N128_train_smooth_b1.npz", **out)
 
 
 def _lean_lct(T, N, bin_len):
@@ -808,7 +848,7 @@ def sec_ingest():
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
             "specular": sec_specular, "bp": sec_bp, "consts_hr": sec_consts_hr, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "e2e128train_smooth": lambda: sec_e2e128train(True), "highres": sec_highres,
-            "e2e512train": sec_e2e512train}
+            "e2e512train": sec_e2e512train, "e2e512train_b1": sec_e2e512train_b1}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -14,6 +14,11 @@ strided 1^3 shortcuts) and weight gradient -- and is spot-checked against float6
 * weight gradient, dense: random operands; 16 x 16 channel blocks x up to 8 taps are reduced over all M rows in
   float64 on the device (torch.matmul -- an M-long reduction per output is not host work at M = 4.2e6 .. 3.4e7).
 
+Bars (relative L2 over the sampled outputs / largest error over the rms of the expected values): 1e-5 / 1e-4 forward and
+data gradient (measured <= 2.2e-6 / 2.5e-5: fp32 rounding of a K <= 131072 sum; ONE dropped product of a K = 16384 sum is
+8e-3 of the rms), 2e-5 / 1e-4 dense weight gradient (measured <= 3.2e-6 / 1.2e-5; a dropped 32-row step of an M = 4.2e6
+reduction is 2.7e-3), 5e-7 / 1e-5 sparse-row weight gradient (measured 8e-8 / 1.4e-6).
+
 Rows are sampled deliberately: the first and last rows of the tensor (last M tile), the rows either side of every
 2^31-byte mark of every tensor the call touches (layer 1's tensors are 4.29 GB: the kernels address rows with 32-bit
 offsets relative to a per-block base and decide on host-side span tests whether they may), and -- for the weight
@@ -173,7 +178,7 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
     if head:
         want = want + bias.double().cpu().numpy()[None, :]
     got = y.reshape(Mo, cout)[rows].cpu().numpy()
-    report.append(("fwd",) + _check(got, want, f"{name} forward", 2e-5, 2e-4))
+    report.append(("fwd",) + _check(got, want, f"{name} forward", 1e-5, 1e-4))
     if stats is not None:
         ym = y.reshape(B, -1, cout)
         s1 = sum(ym[b].sum(0, dtype=torch.float64) for b in range(B))
@@ -195,7 +200,7 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
     patches = _gather(gy, dout, rows_i, din, k, 2 if tr else s, p, divisible=not tr)
     want = patches.double().cpu().numpy().reshape(rows_i.numel(), -1) @ w_dgr
     got = dx.reshape(Mi, cin)[rows_i].cpu().numpy()
-    report.append(("dgrad",) + _check(got, want, f"{name} data gradient", 2e-5, 2e-4))
+    report.append(("dgrad",) + _check(got, want, f"{name} data gradient", 1e-5, 1e-4))
     del patches
     # the fused variants the model uses: the second contribution to the same tensor summed in the epilogue
     stem = name == "stem"
@@ -256,7 +261,7 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
         dense_want.append(blk)
         del pad, sh
     report.append(("wgrad",) + _check(torch.stack(dense_got).cpu().numpy(), torch.stack(dense_want).cpu().numpy(),
-                                      f"{name} weight gradient (dense)", 1e-4, 1e-3))
+                                      f"{name} weight gradient (dense)", 2e-5, 1e-4))
     del gyc, xc, dw, dense_got, dense_want
 
     # sparse: ~40 live rows at the seams -> the FULL dW in float64 on the host
@@ -289,7 +294,7 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
         want = (rows_v.T @ pt.reshape(len(live), -1)).reshape(cout, k ** 3, cin).transpose(0, 2, 1)   # W[co, ci, t]
         del gs
     got = dw.cpu().numpy().reshape(want.shape)
-    report.append((f"wgrad-sparse[{len(live)} rows, msplit {msplit} x {chunk}]",) + _check(got, want, f"{name} weight gradient (sparse rows)", 2e-6, 2e-5))
+    report.append((f"wgrad-sparse[{len(live)} rows, msplit {msplit} x {chunk}]",) + _check(got, want, f"{name} weight gradient (sparse rows)", 5e-7, 1e-5))
     with capsys.disabled():
         print(f"\n[{name:12s} {cin:4d}->{cout:4d} k{k} s{s}{' T' if tr else ''} in{din}] " +
               "  ".join(f"{w_} rel {a:.1e} max {b:.1e}" for w_, a, b in report), end="")
