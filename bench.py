@@ -534,9 +534,11 @@ def main():
                     help="--workload sformer: arithmetic of the per-frame patch attention (BASELINE configs[4] words it "
                          "'MFMA fp16 attention'); default follows --conv-precision")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="opt-in: weight gradients on a second HIP stream (hip_ops.set_wgrad_async). "
-                         "Kernels then overlap, so per-kernel times and the roofline object describe contended launches.")
+    ap.add_argument("--no-wgrad-stream", action="store_true",
+                    help="weight gradients on the main stream (default: on a second HIP stream, hip_ops.set_wgrad_async, so that "
+                         "they overlap the memory-bound BatchNorm passes of backward's critical path).  Per-kernel times and the "
+                         "roofline object always come from appended steps with everything on ONE stream (un-overlapped kernels).")
+    ap.add_argument("--profile-steps", type=int, default=2, help="appended un-overlapped, fully profiled steps (per-kernel table, roofline)")
     ap.add_argument("--dp-algo", default=os.environ.get("HP_DP_ALGO", "all_reduce"), choices=["all_reduce", "rs_ag", "a2a"],
                     help="gradient exchange per bucket (data_parallel.GradBucketReducer): RCCL all-reduce, "
                          "reduce-scatter + all-gather, or direct all-to-all reduce-scatter + all-gather")
@@ -588,9 +590,8 @@ def main():
     if args.batch:
         B = args.batch
     cfg = make_cfg(T, N, device=local, conv_precision=args.conv_precision)
-    if args.wgrad_stream:
-        from hiddenpose_amd import hip_ops as _ops
-        _ops.set_wgrad_async(True)
+    from hiddenpose_amd import hip_ops as _ops
+    _ops.set_wgrad_async(not args.no_wgrad_stream)
     bf16 = args.conv_precision != "fp32"
     # split modes issue 3 / 6 bf16 MFMAs per algorithmic product: the useful-FLOP ceiling shrinks accordingly
     mfma_terms = {"fp32": 1, "bf16": 1, "bf16s": 1, "bf16x3": 3, "bf16x6": 6}[args.conv_precision]
@@ -615,7 +616,17 @@ def main():
 
     reducer_on = reducer is not None
 
+    # A/B hook: HP_MAIN_PRIO=-1 runs the whole step on a HIGH-priority stream (the side stream of the weight gradients keeps
+    # the default, lower priority), so that backward's critical path wins the workgroup slots it can use
+    main_stream = None
+    if os.environ.get("HP_MAIN_PRIO"):
+        main_stream = torch.cuda.Stream(dev, priority=int(os.environ["HP_MAIN_PRIO"]))
+        main_stream.wait_stream(torch.cuda.current_stream(dev))
+
     def step():
+        if main_stream is not None:
+            with torch.cuda.stream(main_stream):
+                return train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
         return train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
 
     def note(msg):
@@ -631,9 +642,10 @@ def main():
              f"(peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)")
     torch.cuda.synchronize()
     _lib.profile_reset()
-    # timed region: HIP events around the matrix-core convolution families only (the roofline candidates); an event
-    # pair per launch of the ~800 small kernels of a step would add ~4 ms/step of pure measurement overhead
-    _lib.profile_enable(2)
+    # timed region: NO per-kernel events (an event pair per launch costs ~4 ms/step over the ~800 launches of a step, and
+    # with the weight gradients on their own stream two kernels are in flight, so a kernel's duration would describe a
+    # contended launch): the per-kernel table and `roofline` come from the appended steps below
+    _lib.profile_enable(False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -647,18 +659,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    _lib.profile_enable(False)
-    prof = _lib.profile_read()
-    # one more step, untimed, with every family profiled: fills the per-kernel table for the remaining kernels
-    # (scaled to args.steps launches so that the table reads per step like the timed entries)
+    # appended, untimed: `--profile-steps` more steps of the same training run with every kernel family bracketed by HIP
+    # events on its launch stream and the weight gradients back on the MAIN stream -- one kernel in flight at a time, so the
+    # durations measure the kernels themselves.  Also timed as a whole: the un-overlapped step, for the A/B on the line.
+    _ops.set_wgrad_async(False)
+    step()                           # the first step after the switch re-times allocator blocks: not profiled
+    torch.cuda.synchronize()
     _lib.profile_reset()
     _lib.profile_enable(1)
-    step()
+    psteps = max(1, args.profile_steps)
+    tp0 = time.perf_counter()
+    for _ in range(psteps):
+        step()
     torch.cuda.synchronize()
+    profiled_ms = 1e3 * (time.perf_counter() - tp0) / psteps
     _lib.profile_enable(False)
-    for k, (n1, ms1) in _lib.profile_read().items():
-        if k not in prof:
-            prof[k] = (n1 * args.steps, ms1 * args.steps)
+    prof = _lib.profile_read()
+    _ops.set_wgrad_async(not args.no_wgrad_stream)
     ranks_seen = [device_identity(local)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -690,7 +707,7 @@ def main():
             "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
                                    f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
                                    "accumulation) with fp32 LCT, U-Net, norms, losses and " + ("bf16 regressor activations / activation gradients in HBM (fp32 raw conv outputs, statistics, weights)" if args.conv_precision == "bf16s" else "fp32 tensors in HBM") if bf16 else "fp32") + ", random-init weights"
-                                   + (", weight gradients on a second stream (kernels overlap)" if args.wgrad_stream and world == 1 else ""),
+                                   + (", weight gradients on a second stream" if not args.no_wgrad_stream else ", weight gradients on the main stream"),
                        "global_batch": B * world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": args.dp_algo if reducer_on else None, "ranks": ranks_seen,
@@ -709,7 +726,7 @@ def main():
             if name in conv and n:
                 # one profiling name covers every layer's launch of that kernel family:
                 # achieved = total algorithmic FLOPs of the family / total time of its launches
-                ach = conv[name] * args.steps / (ms / 1e3) / 1e12
+                ach = conv[name] * psteps / (ms / 1e3) / 1e12
                 roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": mfma_peak,
                         "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4), "traffic": None, "launches": n,
                         "avg_launch_us": round(1e3 * ms / n, 2),
@@ -725,7 +742,7 @@ def main():
                         roof["stale_profile"] = (f"profiles/t512_pmc_hbm_traffic.json was collected at csrc sha "
                                                  f"{fam.get('_csrc_sha')}, this run is {csrc_sha()}: traffic not quoted")
                     elif key:
-                        per_step = n / args.steps
+                        per_step = n / psteps
                         roof["traffic"] = round(fam[key] / per_step, 3)
                         roof["traffic_unit"] = ("GB of HBM per launch, mean over the family's launches (PMC FETCH_SIZE x2 + WRITE_SIZE, "
                                                 "profiles/t512_pmc_hbm_traffic.json, same csrc sha)")
@@ -741,9 +758,15 @@ def main():
                 roof = {"kernel": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                         "frac": round(ach / peak, 4), "traffic": None, "launches": n,
                         "avg_launch_us": round(1e3 * ms / n, 2)}
-            line["hip_kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}
+            line["hip_kernel_ms_per_step"] = {k: round(v[1] / psteps, 3) for k, v in sorted(prof.items())}
+            if roof is not None:
+                roof["note"] = (f"per-kernel times: HIP events over {psteps} appended step(s) of the same run with every kernel on ONE stream "
+                                f"(un-overlapped, {profiled_ms:.1f} ms/step incl. ~4 ms of event overhead); the timed region runs the weight "
+                                "gradients on a second stream" if not args.no_wgrad_stream else
+                                f"per-kernel times: HIP events over {psteps} appended step(s) of the same run")
+            line["unoverlapped_profiled_ms_per_step"] = round(profiled_ms, 3)
             cf = posenet_conv_flops(T, N, B)
-            line["mfma_tflops_by_kernel"] = {k: round(cf[k] * args.steps / (prof[k][1] / 1e3) / 1e12, 1)
+            line["mfma_tflops_by_kernel"] = {k: round(cf[k] * psteps / (prof[k][1] / 1e3) / 1e12, 1)
                                              for k in sorted(cf) if k in prof and prof[k][1] > 0}
         line["roofline"] = roof
         if dist_extra is not None:

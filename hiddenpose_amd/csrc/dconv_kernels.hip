@@ -2013,6 +2013,8 @@ extern "C" int hp_dconv3_forward_fused_p(const float* x, const float* w, const f
 }
 
 extern "C" size_t hp_dconv3_backward_data_workspace_bytes(int B, int cin, int D, int H, int W, int replicate_pad) {
+  // (single-input-channel layers whose output is single-channel too fold inside the stencil kernel and need none; the query
+  // has no cout, so a 1 -> n layer is told the halo volume of its ONE input channel: B * (D+2)(H+2)(W+2) floats)
   return replicate_pad ? sizeof(float) * (size_t)B * cin * (D + 2) * (H + 2) * (W + 2) : 0;
 }
 

@@ -71,7 +71,10 @@ def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0):
     gx = None
     if need_dx:
         gx = torch.empty_like(x)
-        nb = int(L.hp_dconv3_backward_data_workspace_bytes(b, cin, d, h, wd, rp))
+        # the 1 -> 1 layers (FeatureExtraction) fold the replicate padding inside the stencil kernel: no halo workspace
+        # (270 MB at 1024 x 256 x 256) unless the A/B switch puts them back on the matrix-core kernel
+        c1 = cin == 1 and cout == 1 and not int(__import__("os").environ.get("HP_DCONV_C1_MFMA", "0") or 0)
+        nb = 0 if c1 else int(L.hp_dconv3_backward_data_workspace_bytes(b, cin, d, h, wd, rp))
         ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
         ge, we = _emu(g, prec, cin, cout), _emu(w, prec, cin, cout)
         _lib.check(L.hp_dconv3_backward_data_p(ge.data_ptr(), we.data_ptr(), gx.data_ptr(), b, cin, cout, d, h, wd, rp, prec & 1,
@@ -663,14 +666,24 @@ class ResLink:
         self.done = None     # both BatchNorm backwards in one pair of passes and leaves (dz, dgamma, dbeta) here
 
 
-# Opt-in: weight gradients on a second HIP stream.  A weight gradient has no consumer before the optimizer (or the
-# gradient all-reduce), so it can run concurrently with the rest of backward: tails of one GEMM are filled by the
-# other's blocks and the memory-bound BatchNorm passes overlap matrix-core work (542 -> 532 ms/step at the headline
-# workload).  Off by default: with two kernels in flight the per-kernel durations that bench.py's roofline is built
-# from no longer measure the kernels themselves.  HP_WGRAD_STREAM=1 or set_wgrad_async(True) turns it on.
-_WGRAD_ASYNC = bool(int(__import__("os").environ.get("HP_WGRAD_STREAM", "0")))
+# Weight gradients on a second HIP stream (default since round 4; HP_WGRAD_STREAM=0 or set_wgrad_async(False) keeps
+# everything on one stream).  A weight gradient has no consumer before the optimizer (or the gradient all-reduce), so it
+# runs concurrently with the rest of backward: tails of one GEMM are filled by the other's blocks and the memory-bound
+# BatchNorm passes of backward's critical path overlap matrix-core work.  With two kernels in flight a kernel's duration
+# describes a contended launch, so bench.py times the step with the overlap and takes its per-kernel table / roofline from
+# appended steps with the mode switched off.
+_WGRAD_ASYNC = bool(int(__import__("os").environ.get("HP_WGRAD_STREAM", "1")))
 _side_streams = {}
 _joined_task = [-1]
+# Which top-level forward a weight's use count belongs to: `begin_forward()` (called by the regressor's forward) opens a new
+# epoch, so a count left behind by a forward whose backward never ran (validation without no_grad, an exception, a discarded
+# graph) cannot keep a weight off the side stream for the rest of the process; a backward that finds a count from another
+# epoch takes the main stream (always safe).
+_use_epoch = [0]
+
+
+def begin_forward() -> None:
+    _use_epoch[0] += 1
 
 
 def set_wgrad_async(on: bool) -> bool:
@@ -685,7 +698,10 @@ def _wgrad_side_stream(device):
         return None
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device)
+        # LOW priority (HP_WGRAD_PRIO, default 1 = below the default stream's 0; torch clamps to what HIP offers): the main
+        # stream carries backward's critical path (BatchNorm backward -> data gradient -> next unit) and should win every
+        # workgroup slot it can use; the weight gradients fill what is left
+        s = _side_streams[device] = torch.cuda.Stream(device, priority=int(__import__("os").environ.get("HP_WGRAD_PRIO", "1")))
     task = torch._C._current_graph_task_id()
     if _joined_task[0] != task:
         _joined_task[0] = task
@@ -693,11 +709,40 @@ def _wgrad_side_stream(device):
     return s
 
 
+# Operands of weight gradients still queued on a side stream: (event recorded behind the kernel, tensors).  The tensors stay
+# referenced here -- NOT handed to the allocator with record_stream(): a record_stream'ed block is reusable only once the
+# HOST has seen its event complete, and in a training loop the host runs a whole step ahead of the device, so those blocks
+# were never reusable in time, the pool grew until allocation failed and every step paid for the allocator's
+# free-everything-and-synchronize path (measured: 1.2 s instead of 0.47 s per headline step with no host synchronisation
+# between steps).  Instead the MAIN stream waits for the weight gradient of `_HOLD_DEPTH` convolutions ago (a device-side
+# wait, normally already satisfied: the side stream runs one or two kernels behind) and only then is the reference dropped,
+# so the block returns to the allocator as an ordinary main-stream block, in stream order, and at most `_HOLD_DEPTH`
+# convolutions' operands are held beyond their autograd lifetime.
+_held = {}
+_HOLD_DEPTH = int(__import__("os").environ.get("HP_WGRAD_HOLD", "4"))
+
+
+def _hold(device, side, main, tensors):
+    from collections import deque
+    q = _held.get(device)
+    if q is None:
+        q = _held[device] = deque()
+    ev = torch.cuda.Event()
+    ev.record(side)
+    q.append((ev, tensors))
+    while len(q) > _HOLD_DEPTH:
+        ev0, _ = q.popleft()
+        main.wait_event(ev0)     # whatever reuses those blocks on the main stream is ordered behind the kernel that read them
+
+
 def join_side_streams():
     """The current stream of every device waits for the weight gradients queued on its side stream.  Runs by itself
     when the backward pass that queued them ends, i.e. before `backward()` returns to the caller."""
     for dev, s in _side_streams.items():
         torch.cuda.current_stream(dev).wait_stream(s)
+        q = _held.get(dev)
+        if q:
+            q.clear()            # everything queued so far is ordered before whatever the main stream does next
 
 
 def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
@@ -745,19 +790,19 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
         _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), st), "hp_conv3d_unpack_wgrad")
         return dx, dw
     # The weight gradient has no consumer before the optimizer: it runs on a second stream, concurrently with the
-    # rest of backward on the main one (join_side_streams() before the first reader of the gradients).
+    # rest of backward on the main one (join_side_streams() before the first reader of the gradients).  Its output is
+    # allocated HERE, on the main stream (written on the side stream, read and freed on the main one after the join), and its
+    # operands are kept alive by _hold(): no block of this exchange is owned by, or recorded on, the side stream.
     main = torch.cuda.current_stream(x.device)
-    side.wait_stream(main)
     accumulate = w.is_leaf and w.grad is not None
+    dwp = torch.empty(n, dtype=torch.float32, device=x.device)
+    dw = dwp.view_as(w) if _same_as_packed(desc) else torch.empty_like(w)
+    side.wait_stream(main)
     with torch.cuda.stream(side):
         sst = _stream(x)
-        dwp = torch.empty(n, dtype=torch.float32, device=x.device)
         _lib.check(L.hp_conv3d_backward_weight(_C.byref(desc), x.data_ptr(), dz.data_ptr(), dwp.data_ptr(), sst),
                    "hp_conv3d_backward_weight")
-        if _same_as_packed(desc):
-            dw = dwp.view_as(w)
-        else:
-            dw = torch.empty_like(w)
+        if not _same_as_packed(desc):
             _lib.check(L.hp_conv3d_unpack_wgrad(_C.byref(desc), dwp.data_ptr(), dw.data_ptr(), sst), "hp_conv3d_unpack_wgrad")
         if accumulate:
             # `w.grad` already holds something (gradient accumulation over micro-batches, zero_grad(set_to_none=False),
@@ -766,13 +811,14 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
             # gets no gradient for this weight; whoever listens for gradients (the bucket reducer) is told directly.
             with torch.no_grad():
                 w.grad.add_(dw)
-    for t in (x, dz, w):
-        t.record_stream(side)
+    # (dw itself must NOT be held: autograd adopts a gradient tensor as `w.grad` only while nobody else references it, and
+    # would otherwise clone it -- on the main stream, before the side stream has written it)
+    _hold(x.device, side, main, (x, dz, w) if dw.data_ptr() == dwp.data_ptr() else (x, dz, w, dwp))
+    del dwp
     if accumulate:
         for fn in _side_grad_listeners:   # called with the MAIN stream current: a listener orders itself behind both
             fn(w, side)
         return dx, None
-    dw.record_stream(main)
     return dx, dw
 
 
@@ -787,8 +833,10 @@ class _ConvBnAct(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None, res_link=None):
         L = _lib.lib()
         x = x.contiguous()
+        ctx.use_epoch = _use_epoch[0]
         if _WGRAD_ASYNC and torch.is_grad_enabled():
-            w._hp_uses = getattr(w, "_hp_uses", 0) + 1   # a weight used twice in one graph must not take the side stream
+            e, c = getattr(w, "_hp_uses", (-1, 0))      # a weight used twice in one graph must not take the side stream
+            w._hp_uses = (_use_epoch[0], c + 1 if e == _use_epoch[0] else 1)
         cout = w.shape[1] if transposed else w.shape[0]
         desc = _desc(x, cout, k, stride, pad, transposed)
         do, ho, wo = _out_dims(desc)
@@ -899,12 +947,15 @@ class _ConvBnAct(torch.autograd.Function):
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:
                 addend, addend_mask, last = link_in.take()
-            uses = getattr(w, "_hp_uses", 0)
-            if uses > 1:
+            e, uses = getattr(w, "_hp_uses", (-1, 0))
+            stale = uses > 0 and e != ctx.use_epoch   # counted by another forward: nothing is known about this graph
+            if uses > 1 or stale:
                 w._hp_shared = True        # every backward of this weight in this pass stays on the main stream
             dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask)
-            if uses > 0:
-                w._hp_uses = uses - 1
+            if stale:
+                w._hp_shared = False
+            elif uses > 0:
+                w._hp_uses = (e, uses - 1)
                 if uses == 1:
                     w._hp_shared = False
             if not last:           # first of two convolutions reading the block input: park the partial sum

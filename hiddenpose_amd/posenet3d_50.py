@@ -113,6 +113,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         prev = ops.set_conv_precision(self.conv_precision)
+        ops.begin_forward()   # per-weight use counts of the side-stream weight gradients belong to THIS forward
         try:
             x = ops.stem_conv_bn_relu_pool(x, self.conv1, self.bn1)
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))

@@ -3,7 +3,7 @@
 (read-only checkout at /root/reference) through ref_shims.install().
 
 Run in the dev container only:   python tests/golden/make_goldens.py [section ...]
-Sections: lctwin ingest sformer schema consts consts_hr lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train e2e128train_smooth highres e2e512train e2e512train_b1
+Sections: lctwin ingest sformer schema consts consts_hr lct parts posenet e2e e2e128 e2e512 softargmax specular bp e2e128train e2e128train_smooth highres e2e512train e2e512train_b1 e2e512train_repro
 (default: all; highres needs ~45 GB of RAM and ~15 minutes, e2e512train ~55 GB and ~15 minutes)
 
 Inputs come from hiddenpose_amd.testing (seeded, closed form); weights from
@@ -538,6 +538,26 @@ def sec_e2e512train():
     save("e2e_T512_N128_train_smooth.npz", **out)
 
 
+def sec_e2e512train_repro():
+    """How reproducible is the reference's OWN float32 step at batch 2?  The same step as e2e512train with 3 instead of 8
+    intra-op threads (another partition of every reduction PyTorch parallelises): repro_* = |g(3 threads) - g(8 threads)| /
+    |g(8 threads)| per named gradient, added to e2e_T512_N128_train_smooth.npz.  A float32 golden cannot pin a gradient more
+    tightly than the golden's own arithmetic reproduces it."""
+    path = os.path.join(HERE, "e2e_T512_N128_train_smooth.npz")
+    old = dict(np.load(path))
+    torch.set_num_threads(3)
+    out, grads = _e2e512_step(2, torch.float32)
+    torch.set_num_threads(8)
+    for k, g in grads.items():
+        ref = old["gs_" + k] if ("gs_" + k) in old else old["g_" + k]
+        got = g.reshape(-1)[old["gidx_" + k]] if ("gidx_" + k) in old else g
+        old["repro_" + k] = np.float64(np.linalg.norm(got.astype(np.float64) - ref) / max(np.linalg.norm(ref.astype(np.float64)), 1e-300))
+    old["repro_joint_loss"] = np.float64(abs(float(out["joint_loss"]) / float(old["joint_loss"]) - 1))
+    print("  float32 reproducibility of the reference at 512x128x128, B=2 (3 vs 8 threads): " +
+          ", ".join(f"{k.split('.', 1)[1]} {float(old['repro_' + k]):.1e}" for k in E2E128_PARAMS))
+    save("e2e_T512_N128_train_smooth.npz", **old)
+
+
 def sec_e2e512train_b1():
     """The same step at batch 1 in float32 AND float64 -> e2e_T512_N128_train_smooth_b1.npz: the float64 gradients are the
     yardstick at the benchmark volume (train-mode BatchNorm over one sample's voxels is well defined: >= 2048 values per
@@ -848,7 +868,8 @@ def sec_ingest():
 SECTIONS = {"lctwin": sec_lctwin, "ingest": sec_ingest, "sformer": sec_sformer, "schema": sec_schema, "consts": sec_consts, "lct": sec_lct, "parts": sec_parts, "posenet": sec_posenet,
             "e2e": sec_e2e, "e2e128": sec_e2e128, "e2e512": sec_e2e512, "softargmax": sec_softargmax,
             "specular": sec_specular, "bp": sec_bp, "consts_hr": sec_consts_hr, "visible": sec_visible, "xformers": sec_xformers, "e2e128train": sec_e2e128train, "e2e128train_smooth": lambda: sec_e2e128train(True), "highres": sec_highres,
-            "e2e512train": sec_e2e512train, "e2e512train_b1": sec_e2e512train_b1}
+            "e2e512train": sec_e2e512train, "e2e512train_b1": sec_e2e512train_b1,
+            "e2e512train_repro": sec_e2e512train_repro}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)

@@ -469,18 +469,8 @@ def test_train_step_native_128_smooth_filler_gradients_to_1e3(golden, capsys):
     assert tight == 7, tight
 
 
-def test_train_step_benchmark_cube_512_batch2_vs_reference_golden(golden, capsys):
-    """The reference's train step at the BENCHMARK cube (BASELINE configs[1]'s 128 x 128 x 512 volume), batch 2, smooth
-    filler (tests/golden/make_goldens.py e2e512train: the reference's own modules, float32, with the stem and layer1/2
-    blocks under activation checkpointing so that the step fits the dev container): both losses, decoded joints,
-    heat-map / refined-volume samples and the 15 named gradients.  This is the whole-model counterpart of
-    tests/test_conv_headline_gpu.py: the step runs the >= 2 GiB tensors of the stem and layer 1 through every fused
-    BatchNorm / shortcut / gradient-link path of the regressor at the volume the headline number is quoted on.
-    Gradients are compared with the reference's FLOAT32 ones (a float64 twin does not fit), so the bars are the 128^3
-    test's bars plus the reference's own float32 distance from float64 measured there (golden e2e_T128_N128_train_smooth:
-    regressor weights 5e-5 .. 3e-4, stem weight 4e-2 (MaxPool3d's arg-max in float32), everything upstream 1.3e-4 .. 2.3e-3)."""
-    g = golden("e2e_T512_N128_train_smooth.npz")
-    B, T, N = 2, 512, 128
+def _train_step_512(B):
+    T, N = 512, 128
     cfg = make_cfg(T, N)
     model = NlosPose(cfg)
     hpt.fill_module(model, smooth=True)
@@ -492,43 +482,90 @@ def test_train_step_benchmark_cube_512_batch2_vs_reference_golden(golden, capsys
     loss, jl, vl, heat, refine = compute_loss(model, criterion, voxel_criterion, meas, vol, joints)
     optimizer.zero_grad()
     loss.backward()
-    assert abs(jl.item() / float(g["joint_loss"]) - 1) < TOL
-    assert abs(vl.item() / float(g["voxel_loss"]) - 1) < TOL
     tj = softmax_integral_tensor(heat.detach(), 24, True, N // 2, N // 2, T // 2)
-    e_j = hpt.mpjpe(tj.cpu(), torch.from_numpy(g["joints"]))
-    assert e_j < TOL * 64
-    l2 = heat.detach().reshape(B, 24, -1).double().norm(dim=2).cpu().numpy()
-    assert np.abs(l2 / g["heat_l2_per_joint"] - 1).max() < TOL
-    e_h, e_r = rel_l2(heat.detach()[:, :, ::8, ::8, ::8], g["heat_sub"]), rel_l2(refine.detach()[:, :, ::8, ::8, ::8], g["refine_sub"])
-    assert e_h < TOL and e_r < TOL
-    assert abs(float(refine.detach().double().norm()) / float(g["refine_l2"]) - 1) < TOL
+    return model, jl.item(), vl.item(), heat.detach(), refine.detach(), tj
+
+
+def _grad_errors(model, g, sampled_key, full_key):
     named = dict(model.named_parameters())
     keys = [k[4:] for k in g.files if k.startswith("gl2_")]
     assert len(keys) == 15
-    report = {}
+    out = {}
     for k in keys:
         gr = named[k].grad.detach()
         if "gidx_" + k in g.files:
-            e = rel_l2(gr.reshape(-1)[torch.from_numpy(g["gidx_" + k]).cuda()], g["gs_" + k])
+            out[k] = rel_l2(gr.reshape(-1)[torch.from_numpy(g["gidx_" + k]).cuda()], g[sampled_key + k])
         else:
-            e = rel_l2(gr, g["g_" + k])
-        report[k] = e
+            out[k] = rel_l2(gr, g[full_key + k])
+    return named, out
+
+
+def test_train_step_benchmark_cube_512_batch1_vs_reference_float64(golden, capsys):
+    """The reference's train step at the BENCHMARK cube (128 x 128 x 512), batch 1, against the reference's own FLOAT64
+    evaluation of it (tests/golden/make_goldens.py e2e512train_b1; float64 at batch 2 does not fit the dev container --
+    the stem BatchNorm's backward alone holds three 17 GB tensors).  The golden also holds how far the reference's float32
+    step lies from its float64 one at this volume (spread_*): regressor weights 2e-4 .. 6e-4, the head's output convolution
+    7.6e-3, the stem weight 2.9e-1 (MaxPool3d's arg-max decided by float32 noise on the flat background), everything upstream
+    of the regressor 3e-4 .. 1.2e-3.  Bars are absolute: 1e-3 for the losses, joints, heat-maps and every regressor weight
+    gradient (the kernels' exact-fp32 MFMA chains with float64 statistics sit closer to float64 than PyTorch's float32
+    does), 5e-3 for the cancellation-dominated parameters upstream."""
+    g = golden("e2e_T512_N128_train_smooth_b1.npz")
+    model, jl, vl, heat, refine, tj = _train_step_512(1)
+    assert abs(jl / float(g["joint_loss64"]) - 1) < TOL and abs(vl / float(g["voxel_loss64"]) - 1) < TOL
+    e_j = hpt.mpjpe(tj.cpu(), torch.from_numpy(g["joints64"]).float())
+    e_h, e_r = rel_l2(heat[:, :, ::8, ::8, ::8], g["heat_sub64"]), rel_l2(refine[:, :, ::8, ::8, ::8], g["refine_sub64"])
+    assert e_j < TOL * 64 and e_h < TOL and e_r < TOL
+    named, err = _grad_errors(model, g, "gs64_", "g64_")
     with capsys.disabled():
-        print(f"\n[512x128x128 B=2 train step, smooth filler] joint loss {jl.item():.6g} (ref {float(g['joint_loss']):.6g}), voxel loss "
-              f"{vl.item():.6g} (ref {float(g['voxel_loss']):.6g}), MPJPE {e_j:.2e} voxels, heat {e_h:.1e}, refine {e_r:.1e}; "
-              "gradient rel-L2 vs the reference's float32: " + ", ".join(f"{k.split('.', 1)[1]} {a:.1e}" for k, a in report.items()))
+        print(f"\n[512x128x128 B=1 train step vs the reference's float64] joint loss {jl:.7g} (ref64 {float(g['joint_loss64']):.7g}, ref32 "
+              f"{float(g['joint_loss']):.7g}), MPJPE {e_j:.1e} voxels, heat {e_h:.1e}, refine {e_r:.1e}; gradient rel-L2 ours / the reference's "
+              "own float32: " + ", ".join(f"{k.split('.', 1)[1]} {e:.1e}/{float(g['spread_' + k]):.1e}" for k, e in err.items()))
     tight = 0
-    for k, e in report.items():
+    for k, e in err.items():
         if k == "pose_net.head.features.9.bias":   # soft-max shift invariance: the exact gradient is 0
             assert float(named[k].grad.abs().max()) < 1e-2 * float(named["pose_net.head.features.9.weight"].grad.abs().max())
             continue
         regressor = k.startswith("pose_net.") and k != "pose_net.bn1.weight"
-        if k == "pose_net.conv1.weight":
-            bar = 5e-2       # the reference's own float32 gradient of this weight lies 4e-2 from float64 (arg-max ties)
-        elif regressor:
-            bar = 1e-3
-        else:
-            bar = 5e-3       # upstream of the LCT / U-Net: heavy cancellation; reference float32 itself 1.3e-4 .. 2.3e-3 at 128^3
         tight += regressor
-        assert e < bar, (k, e)
-    assert tight == 7, tight
+        assert e < (1e-3 if regressor else 5e-3), (k, e, float(g["spread_" + k]))
+    assert tight == 7
+
+
+def test_train_step_benchmark_cube_512_batch2_vs_reference_golden(golden, capsys):
+    """The reference's train step at the BENCHMARK cube (BASELINE configs[1]'s 128 x 128 x 512 volume), batch 2, smooth
+    filler (tests/golden/make_goldens.py e2e512train: the reference's own modules, float32, with the stem and layer1/2
+    blocks under activation checkpointing so that the step fits the dev container): both losses, decoded joints,
+    heat-map / refined-volume samples and the 15 named gradients.  This is the whole-model counterpart of
+    tests/test_conv_headline_gpu.py: the step runs the > 2 GiB tensors of the stem and layer 1 through every fused
+    BatchNorm / shortcut / gradient-link path of the regressor at the volume the headline number is quoted on.
+    The golden is the reference's FLOAT32 step (a float64 twin of this batch does not fit), so a gradient can only be held
+    to the reference's own float32 noise: bar = max(1e-3, 3 x the distance between the reference's float32 and float64
+    gradients of that parameter measured at this volume, batch 1 -- golden e2e_T512_N128_train_smooth_b1, spread_*).  The
+    tight statement about OUR gradients at this volume is the batch-1 test above (against float64)."""
+    g = golden("e2e_T512_N128_train_smooth.npz")
+    g1 = golden("e2e_T512_N128_train_smooth_b1.npz")
+    B, T, N = 2, 512, 128
+    model, jl, vl, heat, refine, tj = _train_step_512(B)
+    assert abs(jl / float(g["joint_loss"]) - 1) < TOL and abs(vl / float(g["voxel_loss"]) - 1) < TOL
+    e_j = hpt.mpjpe(tj.cpu(), torch.from_numpy(g["joints"]))
+    l2 = heat.reshape(B, 24, -1).double().norm(dim=2).cpu().numpy()
+    e_h, e_r = rel_l2(heat[:, :, ::8, ::8, ::8], g["heat_sub"]), rel_l2(refine[:, :, ::8, ::8, ::8], g["refine_sub"])
+    assert e_j < TOL * 64 and np.abs(l2 / g["heat_l2_per_joint"] - 1).max() < TOL and e_h < TOL and e_r < TOL
+    assert abs(float(refine.double().norm()) / float(g["refine_l2"]) - 1) < TOL
+    named, err = _grad_errors(model, g, "gs_", "g_")
+    with capsys.disabled():
+        print(f"\n[512x128x128 B=2 train step vs the reference's float32] joint loss {jl:.7g} (ref {float(g['joint_loss']):.7g}), voxel loss "
+              f"{vl:.7g} (ref {float(g['voxel_loss']):.7g}), MPJPE {e_j:.1e} voxels, heat {e_h:.1e}, refine {e_r:.1e}; gradient rel-L2 / "
+              "the reference's float32-float64 distance at batch 1: " +
+              ", ".join(f"{k.split('.', 1)[1]} {e:.1e}/{float(g1['spread_' + k]):.1e}" for k, e in err.items()))
+    for k, e in err.items():
+        if k == "pose_net.head.features.9.bias":   # soft-max shift invariance: the exact gradient is 0
+            assert float(named[k].grad.abs().max()) < 1e-2 * float(named["pose_net.head.features.9.weight"].grad.abs().max())
+            continue
+        if k in ("autoencoder.out.conv.bias", "feature_extraction.weights", "feature_extraction.conv1.3.tmp.4.bias"):
+            # sums of a sign-mixed gradient over all 2 x 8.4e6 voxels that all but cancel (out.conv.bias: the total is ~1e-2 of ONE
+            # voxel's rms, so 2^-24 sqrt(n) of rounding is percent-level): float32 against float32 here measured 5.2e-2, 1.1e-2,
+            # 5.9e-3; against float64 (batch 1, above) ours are 3.9e-4, 1.2e-3, 6.2e-4 from the truth
+            assert e < (0.15 if k.endswith("out.conv.bias") else 3e-2), (k, e)
+            continue
+        assert e < max(1e-3, 3.0 * float(g1["spread_" + k])), (k, e, float(g1["spread_" + k]))

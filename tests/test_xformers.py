@@ -136,3 +136,66 @@ def test_geglu_in_the_gemm_epilogue_equals_the_three_launch_form(rows, dim, hid,
         lin_in.bias.mul_(0.5)
     fused2 = X.geglu_ff(x0.cuda(), hc, lin_in, lin_out, P)
     assert rel_l2(fused2, fused) > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("rows,dim,hid", [(517, 96, 64), (384, 256, 1024), (131, 64, 192), (1025, 32, 128)])
+def test_linear_and_geglu_epilogues_write_only_their_output(rows, dim, hid, prec):
+    """Regression net for round 3's run-51 fault (a GEGLU epilogue store that left its half-width output): the
+    outputs of hp_linear_geglu_forward and hp_linear_forward (bias + in-place residual, N not a multiple of the tile) sit
+    between two guard regions filled with a sentinel; after the call the guards are untouched bit for bit, every output
+    element was written, and the values equal the float64 evaluation.  Whole tiles, the ragged last M tile and a single
+    128-column tile (hid = 64) in every arithmetic mode, i.e. every epilogue branch of k_igemm<128> / <64>."""
+    from hiddenpose_amd import _lib
+    from hiddenpose_amd import _xformer as X
+
+    L = _lib.lib()
+    P = X.PREC[prec]
+    tol = {"fp32": 2e-6, "bf16": 2e-2, "bf16x3": 1e-4}[prec]
+    g = torch.Generator().manual_seed(rows * 7 + hid)
+    h = torch.randn(rows, dim, generator=g)
+    w1 = torch.randn(2 * hid, dim, generator=g) * dim ** -0.5
+    b1 = torch.randn(2 * hid, generator=g) * 0.5
+    lin = torch.nn.Linear(dim, 2 * hid)
+    with torch.no_grad():
+        lin.weight.copy_(w1)
+        lin.bias.copy_(b1)
+    lin = lin.cuda()
+    hc = h.cuda()
+    st = X._st(hc)
+    GUARD = 64 * 1024                                  # floats either side (256 KB: beyond any tile a slip could reach)
+    SENT = float.fromhex("0x1.5a5a5ap+100")
+
+    def guarded(n):
+        buf = torch.full((GUARD + n + GUARD,), SENT, device="cuda")
+        return buf, buf[GUARD:GUARD + n]
+
+    def intact(buf, n):
+        return bool((buf[:GUARD] == SENT).all()) and bool((buf[GUARD + n:] == SENT).all())
+
+    # GEGLU epilogue: y (rows, hid) = u[:, :hid] * gelu(u[:, hid:])
+    wp, bp = X._paired_rows(lin)
+    buf, y = guarded(rows * hid)
+    _lib.check(L.hp_linear_geglu_forward(hc.data_ptr(), wp.data_ptr(), bp.data_ptr(), y.data_ptr(), rows, dim, 2 * hid, P, st),
+               "hp_linear_geglu_forward")
+    torch.cuda.synchronize()
+    assert intact(buf, rows * hid), "GEGLU epilogue wrote outside its (rows, hidden) output"
+    assert not bool((y == SENT).any()), "GEGLU epilogue left output elements unwritten"
+    u = torch.nn.functional.linear(h.double(), w1.double(), b1.double())
+    ref = u[:, :hid] * torch.nn.functional.gelu(u[:, hid:])
+    assert rel_l2(y.view(rows, hid), ref) < tol
+    # plain Linear with bias and an in-place residual, N = dim (32 .. 256: partial and whole column tiles)
+    w2 = torch.randn(dim, hid, generator=g) * hid ** -0.5
+    b2 = torch.randn(dim, generator=g) * 0.5
+    x0 = torch.randn(rows, dim, generator=g)
+    a = torch.randn(rows, hid, generator=g)
+    buf2, y2 = guarded(rows * dim)
+    y2.copy_(x0.reshape(-1).cuda())
+    ac, w2c, b2c = a.cuda(), w2.cuda(), b2.cuda()      # named: a temporary would be freed (and its block reused) before the launch
+    _lib.check(L.hp_linear_forward(ac.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), y2.data_ptr(), y2.data_ptr(), rows, hid, dim, P, st),
+               "hp_linear_forward")
+    torch.cuda.synchronize()
+    assert intact(buf2, rows * dim), "Linear epilogue wrote outside its (rows, N) output"
+    ref2 = x0.double() + torch.nn.functional.linear(a.double(), w2.double(), b2.double())
+    assert rel_l2(y2.view(rows, dim), ref2) < tol
