@@ -210,7 +210,7 @@ def cpu_baseline(threads: int, full: bool = False):
             "scaled_from": "one 128x128x128 cube = 1/4 of a 128x128x512 sample (times x4)",
             "train_step_s_per_cube": round(t_train, 3), "forward_s_per_cube": round(t_fwd, 3),
             "forward_value": round(0.25 / t_fwd, 6),
-            "sample": f"1 cube of 128x128x128, oracle (torch CPU fp32, {threads} threads): forward + losses {t_fwd:.2f} s, "
+            "sample": f"batch 1 (B=1): 1 cube of 128x128x128, oracle (torch CPU fp32, {threads} threads): forward + losses {t_fwd:.2f} s, "
                       f"forward + losses + backward + Adam {t_train:.2f} s (medians of 3 after 1 warm-up); value = train leg / 4"}
 
 
@@ -353,8 +353,9 @@ def bench_highres(args, emit=True, also_bf16=False):
     fp.method.plan_for(meas.device)
     print(f"[bench] constants + plan for T={T} N={N}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
 
-    # --conv-precision bf16 / bf16s: the multi-channel 3^3 convolutions on the bf16 matrix cores (forward and data gradient;
-    # fp32 tensors, fp32 accumulation, fp32 LCT / norms / weight gradients), as in BASELINE configs[2]
+    # --conv-precision bf16 / bf16s: the multi-channel 3^3 convolutions on the bf16 matrix cores -- forward, data gradient AND
+    # weight gradient (hip_ops._DCONV_WGRAD_BF16, on unless HP_DCONV_WGRAD_BF16=0); fp32 tensors, fp32 accumulation, fp32 LCT /
+    # norms.  (In the NlosPose model this arithmetic is opt-in: MODEL.DCONV_PRECISION = 'bf16'.)
     dconv_bf16 = getattr(args, "conv_precision", "fp32") in ("bf16", "bf16s")
     ops.set_dconv_precision("bf16" if dconv_bf16 else "fp32")
 
@@ -395,7 +396,7 @@ def bench_highres(args, emit=True, also_bf16=False):
         "metric": "samples/sec (256x256x1024 meas) FE+LCT+normalize+UNet fwd+bwd", "value": round(B * args.steps / dt, 3),
         "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 tensors and LCT; multi-channel 3^3 convolutions fwd / data gradient with bf16 operands (MFMA 4x4x4), f32 accumulation"
+        "dtype": "f32 tensors and LCT; multi-channel 3^3 convolutions fwd / data gradient / weight gradient with bf16 operands (MFMA 4x4x4), f32 accumulation"
                  if dconv_bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"FeatureExtraction+LCT+normalize_feature+UNet3d fwd+bwd, {N}x{N}x{T}, batch {B}"},
         "hip_kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items()) if v[1] / args.steps > 0.05},
@@ -409,7 +410,7 @@ def bench_highres(args, emit=True, also_bf16=False):
                                       "achieved_tflops": round(conv_gflop / conv_ms, 1) if conv_ms else None,
                                       "peak_tflops": MFMA_F32_PEAK_TFLOPS if not dconv_bf16 else None}}
     if also_bf16 and not dconv_bf16:
-        # the same step with the multi-channel convolutions' forward / data gradient on the bf16 matrix cores (configs[2] arithmetic)
+        # the same step with the multi-channel convolutions (forward, data gradient, weight gradient) on the bf16 matrix cores
         ops.set_dconv_precision("bf16")
         for _ in range(max(1, args.warmup)):
             step()
@@ -426,7 +427,7 @@ def bench_highres(args, emit=True, also_bf16=False):
         pb = _lib.profile_read()
         line["bf16_thin_channel"] = {
             "ms_per_step": round(1e3 * dtb / args.steps, 3), "value": round(B * args.steps / dtb, 3), "unit": "samples/s",
-            "dtype": "f32 tensors and LCT; multi-channel 3^3 convolutions fwd / data gradient with bf16 operands (MFMA 4x4x4)",
+            "dtype": "f32 tensors and LCT; multi-channel 3^3 convolutions fwd / data gradient / weight gradient with bf16 operands (MFMA 4x4x4)",
             "thin_channel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(pb.items()) if k.startswith("dconv3_")}}
     if emit:
         print(json.dumps(line), flush=True)
@@ -468,6 +469,8 @@ def quick_native(args, local, note, workload="native", precision=None, label="re
         dist.barrier()
         torch.cuda.synchronize()
     steps = 3
+    if reducer is not None:
+        reducer.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints, reducer)
@@ -480,7 +483,9 @@ def quick_native(args, local, note, workload="native", precision=None, label="re
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    dp_timing = None
     if reducer is not None:
+        dp_timing = reducer.read_timing()
         reducer.remove_hooks()
     note(f"extra: {N}x{N}x{T} batch {B}/GPU x {world} {precision}: {1e3 * dt / steps:.1f} ms/step")
     out = {"workload": f"NlosPose train step, {N}x{N}x{T} ({label}), batch {B}" + ("/GPU" if world > 1 else "") + f", {precision}",
@@ -488,7 +493,20 @@ def quick_native(args, local, note, workload="native", precision=None, label="re
            "warmup": 1}
     if world > 1:
         out.update({"n_gpus": world, "global_batch": B * world,
-                    "parallelism": f"dp{world} ({dist_ctx[2]}, {'bf16' if precision != 'fp32' else 'fp32'} wire)"})
+                    "parallelism": f"dp{world} ({dist_ctx[2]}, {'bf16' if precision != 'fp32' else 'fp32'} wire)",
+                    "dp_timing": dp_timing})
+    return out
+
+
+def collective_library_info() -> dict:
+    """Versions a reader needs next to a multi-GPU number (torch.distributed 'nccl' IS RCCL on ROCm)."""
+    import torch.distributed as dist
+    out = {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
+           "backend": dist.get_backend() if dist.is_initialized() else None}
+    try:
+        out["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001  (gloo rehearsal, CPU build)
+        out["rccl"] = f"unavailable ({type(e).__name__})"
     return out
 
 
@@ -646,6 +664,8 @@ def main():
     # with the weight gradients on their own stream two kernels are in flight, so a kernel's duration would describe a
     # contended launch): the per-kernel table and `roofline` come from the appended steps below
     _lib.profile_enable(False)
+    if reducer is not None:
+        reducer.enable_timing(True)  # a pair of events per bucket on the communication stream + one pair around finish()'s wait
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -659,6 +679,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dp_timing = None
+    if reducer is not None:
+        dp_timing = reducer.read_timing()
+        reducer.enable_timing(False)
     # appended, untimed: `--profile-steps` more steps of the same training run with every kernel family bracketed by HIP
     # events on its launch stream and the weight gradients back on the MAIN stream -- one kernel in flight at a time, so the
     # durations measure the kernels themselves.  Also timed as a whole: the un-overlapped step, for the A/B on the line.
@@ -676,6 +700,35 @@ def main():
     _lib.profile_enable(False)
     prof = _lib.profile_read()
     _ops.set_wgrad_async(not args.no_wgrad_stream)
+    dp_ab = None
+    if reducer is not None and not args.no_extra:
+        # the same step with each exchange algorithm, 3 timed steps each (1 warm-up), slowest rank: the first multi-GPU run
+        # A/Bs them by itself (the xGMI mesh favours the direct forms, nothing here has measured it)
+        dp_ab = {}
+        for algo in ("all_reduce", "rs_ag", "a2a"):
+            reducer.remove_hooks()
+            reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, force_collectives=force, algo=algo, wire_dtype=wire)
+            step()
+            torch.cuda.synchronize()
+            reducer.enable_timing(True)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            tb = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            tm = reducer.read_timing()
+            dp_ab[algo] = {"ms_per_step": round(1e3 * float(tb.item()) / 3, 3), "exchange_ms_per_step": tm["exchange_ms_per_step"],
+                           "exposed_ms_per_step": tm["exposed_ms_per_step"]}
+            note(f"dp-algo A/B {algo}: {dp_ab[algo]}")
+        reducer.remove_hooks()
+        reducer = GradBucketReducer(model, bucket_mb=args.bucket_mb, force_collectives=force, algo=args.dp_algo, wire_dtype=wire)
     ranks_seen = [device_identity(local)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -711,6 +764,12 @@ def main():
                        "global_batch": B * world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": args.dp_algo if reducer_on else None, "ranks": ranks_seen,
+                       # what a reader needs to explain the FIRST multi-GPU run from this one line: library versions, the
+                       # communication-related environment in effect, per-bucket exchange times and the exposed communication
+                       "collective_library": collective_library_info() if reducer_on else None,
+                       "comm_env": {k: v for k, v in sorted(os.environ.items())
+                                    if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_", "HP_DP_", "HP_WGRAD", "HP_DIST", "HP_SHARE", "TORCH_NCCL"))},
+                       "dp_timing": dp_timing,
                        "parallelism": f"dp{world}" + (f" ({args.dp_algo}, {'bf16' if wire is not None else 'fp32'} wire, "
                                                       f"{args.bucket_mb:g} MB buckets)" if reducer_on else ""), "hip_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).HIP_STAGES),
                        "aten_stages": sorted(__import__("hiddenpose_amd.hip_ops", fromlist=["x"]).ATEN_STAGES)},
@@ -771,6 +830,8 @@ def main():
         line["roofline"] = roof
         if dist_extra is not None:
             line["extra"] = {"configs2_bf16s_dp": dist_extra}
+        if dp_ab is not None:
+            line.setdefault("extra", {})["dp_algo_ab"] = dp_ab
         if world == 1 and args.workload == "t512" and not args.no_extra:
             # SURVEY 8(d) names two shapes for configs[1]: the BASELINE-worded 128x128x512 cube (the headline above) and
             # the reference's own training shape 128^3 (train.py:77-86); the second is reported here, same step, same batch

@@ -54,23 +54,6 @@ def attention(h2d, to_qkv, b, ntok, heads, dh, nj, n, frames, scale, sin_t=None,
     return att
 
 
-def _paired_rows(lin_in):
-    """The GEGLU input Linear's rows in the order hp_linear_geglu_forward wants: every 128 rows = 64 value rows followed by
-    their 64 gate rows.  Cached ON the module (an id()-keyed table would hand a new module the rows of a dead one whose id,
-    storage address and version counters it happens to reuse) and recomputed when a parameter was written to (`_version`),
-    replaced or moved."""
-    w, b = lin_in.weight, lin_in.bias
-    ver = (id(w), w._version, w.data_ptr(), w.device, None if b is None else (id(b), b._version, b.data_ptr()))
-    hit = getattr(lin_in, "_hp_paired_rows", None)
-    if hit is None or hit[0] != ver or hit[1] is not w:
-        hid = w.shape[0] // 2
-        idx = torch.arange(hid, device=w.device).view(-1, 64)
-        order = torch.cat((idx, idx + hid), dim=1).reshape(-1)
-        hit = (ver, w, w.detach().index_select(0, order).contiguous(), None if b is None else b.detach().index_select(0, order).contiguous())
-        object.__setattr__(lin_in, "_hp_paired_rows", hit)   # (plain attribute: not a buffer, not in the state_dict)
-    return hit[2], hit[3]
-
-
 def geglu_ff(x2d_resid, h2d, lin_in, lin_out, precision=0):
     """x += W2 (u[:, :H] * gelu(u[:, H:])),  u = W1 h  (models/transformer.py:58-74).  With a hidden width that is a multiple
     of 64 the GEGLU rides in the first GEMM's epilogue (u is never written); otherwise Linear, hp_geglu_forward, Linear."""
@@ -78,9 +61,9 @@ def geglu_ff(x2d_resid, h2d, lin_in, lin_out, precision=0):
     rows = h2d.shape[0]
     g = torch.empty(rows, hid, dtype=torch.float32, device=h2d.device)
     if hid % 64 == 0 and lin_in.weight.shape[0] == 2 * hid:
-        wp, bp = _paired_rows(lin_in)
-        _lib.check(_lib.lib().hp_linear_geglu_forward(h2d.data_ptr(), wp.data_ptr(), _lib.ptr(bp), g.data_ptr(), rows, h2d.shape[1],
-                                                      2 * hid, precision, _st(h2d)), "hp_linear_geglu_forward")
+        # the Linear's own weight / bias: the kernel pairs value and gate rows inside its gather (no cached reordered copy)
+        _lib.check(_lib.lib().hp_linear_geglu_forward(h2d.data_ptr(), lin_in.weight.data_ptr(), _lib.ptr(lin_in.bias), g.data_ptr(), rows,
+                                                      h2d.shape[1], 2 * hid, precision, _st(h2d)), "hp_linear_geglu_forward")
     else:
         u = linear(h2d, lin_in.weight, lin_in.bias, precision)
         _lib.check(_lib.lib().hp_geglu_forward(u.data_ptr(), g.data_ptr(), rows, hid, _st(h2d)), "hp_geglu_forward")

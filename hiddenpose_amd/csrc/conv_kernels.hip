@@ -315,7 +315,10 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
   for (int i = 0; i < BN / 32; ++i) {
     const int n = n0 + r0 + 32 * i;
     wvalid[i] = n < g.Nout;
-    wrow[i] = (long)n * g.Cin + kq * EPL;
+    // GEGLU epilogue: column c of the 128-column tile t is the Linear's row 64 t + c (c < 64: value) or hidden + 64 t + c - 64
+    // (gate) -- the pairing is done HERE, in the gather's row index, so no reordered copy of the weights exists anywhere
+    const int nsrc = g.geglu ? ((n & 64) ? (g.Nout >> 1) + ((n >> 7) << 6) + (n & 63) : ((n >> 7) << 6) + (n & 63)) : n;
+    wrow[i] = (long)nsrc * g.Cin + kq * EPL;
   }
 
   // BL: descriptors (wave-uniform) and per-thread byte offsets
@@ -722,9 +725,9 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           float* const yg = (float*)Y + m0 * (long)(g.Nout / 2) + n0 / 2;
           float4 bv4 = make_float4(0, 0, 0, 0), bg4 = bv4;
           const int qg = tid % QH, rg = tid / QH;
-          if (bias) {
-            bv4 = *(const float4*)(bias + n0 + 4 * qg);
-            bg4 = *(const float4*)(bias + n0 + BN / 2 + 4 * qg);
+          if (bias) {   // the Linear's own bias: value entries n0 / 2 .., gate entries hidden + n0 / 2 ..
+            bv4 = *(const float4*)(bias + n0 / 2 + 4 * qg);
+            bg4 = *(const float4*)(bias + g.Nout / 2 + n0 / 2 + 4 * qg);
           }
           auto gl = [](float a, float t) { return a * 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); };
 #pragma unroll
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
             if (q >= Q / 2) continue;
             float4 gt = *(const float4*)(smem + row64 * LDO + 4 * q + BN / 2);
             if (bias) {
-              const float4 bv = *(const float4*)(bias + n), bg = *(const float4*)(bias + n + BN / 2);
+              const float4 bv = *(const float4*)(bias + n0 / 2 + 4 * q), bg = *(const float4*)(bias + g.Nout / 2 + n0 / 2 + 4 * q);
               v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
               gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
             }
@@ -2908,9 +2911,9 @@ extern "C" int hp_linear_forward(const float* x, const float* w, const float* bi
   return HP_OK;
 }
 
-extern "C" int hp_linear_geglu_forward(const float* x, const float* w_paired, const float* bias_paired, float* y, long M, int K,
+extern "C" int hp_linear_geglu_forward(const float* x, const float* w, const float* bias, float* y, long M, int K,
                                        int N2, int precision, void* stream) {
-  HP_REQUIRE(x && w_paired && y && M >= 1 && M < (1l << 31) && K >= 4, "hp_linear_geglu_forward: bad argument");
+  HP_REQUIRE(x && w && y && M >= 1 && M < (1l << 31) && K >= 4, "hp_linear_geglu_forward: bad argument");
   HP_REQUIRE(N2 >= 128 && N2 % 128 == 0, "hp_linear_geglu_forward: 2 * hidden must be a multiple of 128 (got %d)", N2);
   hp_conv_desc d{1, 1, 1, (int)M, K, N2, 1, 1, 0, 0, precision, 0};
   ConvPlan p;
@@ -2920,7 +2923,7 @@ extern "C" int hp_linear_geglu_forward(const float* x, const float* w_paired, co
   hipStream_t st = (hipStream_t)stream;
   {
     HP_PROF("linear_fwd", st);
-    launch_igemm(p.fwd, 1, false, p.planes, x, w_paired, bias_paired, y, nullptr, nullptr, st);
+    launch_igemm(p.fwd, 1, false, p.planes, x, w, bias, y, nullptr, nullptr, st);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

@@ -89,6 +89,13 @@ class GradBucketReducer:
         self._cuda = self.flat[0].is_cuda
         self._comm_stream = torch.cuda.Stream(self.flat[0].device) if (self._cuda and self._active) else None
         self._side = None
+        # Optional instrumentation (enable_timing): per bucket, a pair of events on the communication stream around its
+        # exchange; per step, a pair on the training stream around finish()'s wait -- the communication time that backward did
+        # NOT hide ("exposed").  Off by default: nothing is recorded.
+        self._timing = False
+        self._t_bucket = [[] for _ in self.buckets]
+        self._t_exposed = []
+        self._t_host = [[] for _ in self.buckets]     # CPU tensors (gloo): host seconds per exchange
         if self._active:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -155,14 +162,53 @@ class GradBucketReducer:
     def _launch(self, bi: int) -> None:
         flat = self.flat[bi]
         if self._comm_stream is None:
-            self._exchange(bi)
+            if self._timing:
+                import time
+                t0 = time.perf_counter()
+                self._exchange(bi)
+                self._t_host[bi].append(time.perf_counter() - t0)
+            else:
+                self._exchange(bi)
             return
         cs = self._comm_stream
         cs.wait_stream(torch.cuda.current_stream(flat.device))
         if self._side is not None:
             cs.wait_stream(self._side)
         with torch.cuda.stream(cs):
-            self._exchange(bi)
+            if self._timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cs)
+                self._exchange(bi)
+                b.record(cs)
+                self._t_bucket[bi].append((a, b))
+            else:
+                self._exchange(bi)
+
+    # -- instrumentation
+    def enable_timing(self, on: bool = True) -> None:
+        self._timing = bool(on) and self._active
+        self._t_bucket = [[] for _ in self.buckets]
+        self._t_exposed = []
+        self._t_host = [[] for _ in self.buckets]
+
+    def read_timing(self) -> dict:
+        """Means over the steps since enable_timing(): per-bucket exchange time on the communication stream (cast to the wire
+        dtype + collective(s) + cast back), the bucket sizes, and the exposed communication per step (how long the training
+        stream waited in finish()).  Synchronises the device."""
+        if self._cuda:
+            torch.cuda.synchronize(self.flat[0].device)
+            per_bucket = [round(sum(a.elapsed_time(b) for a, b in ev) / len(ev), 4) if ev else None for ev in self._t_bucket]
+            exposed = [a.elapsed_time(b) for a, b in self._t_exposed]
+        else:
+            per_bucket = [round(1e3 * sum(v) / len(v), 4) if v else None for v in self._t_host]
+            exposed = [1e3 * v for v in self._t_exposed]
+        wire_b = 2 if self.wire_dtype == torch.bfloat16 else self.flat[0].element_size()
+        return {"algo": self.algo, "wire_dtype": str(self.wire_dtype or self.flat[0].dtype).replace("torch.", ""),
+                "bucket_mb": [round(f.numel() * wire_b / 2**20, 2) for f in self.flat],
+                "bucket_exchange_ms": per_bucket,
+                "exchange_ms_per_step": round(sum(v for v in per_bucket if v is not None), 4),
+                "exposed_ms_per_step": round(sum(exposed) / len(exposed), 4) if exposed else None,
+                "steps_timed": len(exposed)}
 
     def finish(self) -> None:
         """Wait for every bucket (buckets whose parameters got no gradient this step are
@@ -173,7 +219,17 @@ class GradBucketReducer:
                     self._pending[bi] = 0
                     self._launch(bi)
             if self._comm_stream is not None:
-                torch.cuda.current_stream(self.flat[0].device).wait_stream(self._comm_stream)
+                main = torch.cuda.current_stream(self.flat[0].device)
+                if self._timing:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(main)
+                    main.wait_stream(self._comm_stream)
+                    b.record(main)
+                    self._t_exposed.append((a, b))
+                else:
+                    main.wait_stream(self._comm_stream)
+            elif self._timing:
+                self._t_exposed.append(0.0)      # synchronous collectives (CPU tensors): all of it is exposed, see bucket times
 
     def remove_hooks(self) -> None:
         for h in self._hooks:

@@ -811,10 +811,12 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
             # gets no gradient for this weight; whoever listens for gradients (the bucket reducer) is told directly.
             with torch.no_grad():
                 w.grad.add_(dw)
-    # (dw itself must NOT be held: autograd adopts a gradient tensor as `w.grad` only while nobody else references it, and
-    # would otherwise clone it -- on the main stream, before the side stream has written it)
-    _hold(x.device, side, main, (x, dz, w) if dw.data_ptr() == dwp.data_ptr() else (x, dz, w, dwp))
-    del dwp
+    # (a dw that goes to autograd must NOT be held: autograd adopts a gradient tensor as `w.grad` only while nobody else
+    # references it, and would otherwise clone it -- on the main stream, before the side stream has written it.  A dw that was
+    # summed into w.grad above dies with this call and MUST be held: its block was allocated on the main stream.)
+    keep = (x, dz, w, dwp, dw) if accumulate else ((x, dz, w) if dw.data_ptr() == dwp.data_ptr() else (x, dz, w, dwp))
+    _hold(x.device, side, main, keep)
+    del dwp, keep
     if accumulate:
         for fn in _side_grad_listeners:   # called with the MAIN stream current: a listener orders itself behind both
             fn(w, side)

@@ -393,11 +393,12 @@ int hp_bce_dice_backward_scaled(const float* logit, const float* target, const d
 int hp_linear_forward(const float* x, const float* w, const float* bias, const float* addend, float* y, long M, int K, int N,
                       int precision, void* stream);
 /* The feed-forward's first Linear with its GEGLU (models/NlosPoseSformer.py:252-262: `x, gates = u.chunk(2, dim=-1);
- * x * gelu(gates)`) in the GEMM's epilogue: u (M, 2*hidden) is never written.  w_paired (N2 = 2*hidden, K) and bias_paired
- * (N2, may be NULL) are the Linear's rows REORDERED so that every run of 128 rows holds 64 value rows followed by their 64
- * gate rows: paired[128 t + c] = w[64 t + c], paired[128 t + 64 + c] = w[hidden + 64 t + c] (c < 64).  y: (M, hidden).
- * N2 % 128 == 0.  Same arithmetic choices as hp_linear_forward. */
-int hp_linear_geglu_forward(const float* x, const float* w_paired, const float* bias_paired, float* y, long M, int K, int N2,
+ * x * gelu(gates)`) in the GEMM's epilogue: u (M, 2*hidden) is never written.  w (N2 = 2*hidden, K) and bias (N2, may be
+ * NULL) are the Linear's OWN parameters, as they lie in its state_dict: the kernel pairs value row 64 t + c with gate row
+ * hidden + 64 t + c inside its weight gather (one 128-column tile = 64 values + their 64 gates), so no reordered copy of the
+ * weights exists (round 3 took a pre-paired copy, which a `param.data` write could leave stale).  y: (M, hidden).
+ * hidden % 64 == 0, i.e. N2 % 128 == 0.  Same arithmetic choices as hp_linear_forward. */
+int hp_linear_geglu_forward(const float* x, const float* w, const float* bias, float* y, long M, int K, int N2,
                             int precision, void* stream);
 /* rearrange 'b f c (h p1) (w p2) -> (b f h w) (p1 p2 c)'  (:104) */
 int hp_sformer_patchify(const float* video, float* tokens, int B, int frames, int C, int H, int W, int patch,

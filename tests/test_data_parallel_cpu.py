@@ -51,6 +51,7 @@ def _worker(rank, world, port, out, algo="all_reduce", wire=None):
             for p in model.parameters():
                 p.add_(1.0)
     red = GradBucketReducer(model, bucket_mb=0.002, algo=algo, wire_dtype=wire)  # ~2 KB buckets -> several buckets
+    red.enable_timing(True)   # instrumentation on: per-bucket exchange times, exposed time (must not change any result)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     g = torch.Generator().manual_seed(100 + rank)
     for step in range(2):
@@ -71,7 +72,8 @@ def _worker(rank, world, port, out, algo="all_reduce", wire=None):
     dl, dg = _dice_rank_loss_and_grad(xl, tl, world)
     dist.all_reduce(dl)
     dl /= world              # what averaging the per-rank losses reports
-    out[rank] = {"dice_loss": dl.item(), "dice_grad": dg / world,   # / world: the reducer's gradient averaging
+    tm = red.read_timing()
+    out[rank] = {"timing": tm, "dice_loss": dl.item(), "dice_grad": dg / world,   # / world: the reducer's gradient averaging
 "nb": len(red.buckets), "grads0": grads0, "params": [p.detach().clone() for p in model.parameters()],
                  "dice": (i.item(), p_.item(), t.item()),
                  "views": all(p.grad.data_ptr() >= red.flat[red._bucket_of[p]].data_ptr() for p in model.parameters())}
@@ -86,6 +88,9 @@ def test_bucketed_allreduce_world2(algo, wire):
     mp.spawn(_worker, args=(world, port, out, algo, wire), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
     assert r0["nb"] > 1 and r0["views"] and r1["views"]
+    tm = r0["timing"]
+    assert tm["algo"] == algo and tm["steps_timed"] == 2 and len(tm["bucket_exchange_ms"]) == r0["nb"] == len(tm["bucket_mb"])
+    assert all(v is not None and v > 0 for v in tm["bucket_exchange_ms"]) and tm["wire_dtype"] == ("bfloat16" if wire else "float32")
     # expected step-0 gradient: average of the two ranks' local gradients from rank 0's weights
     exp = None
     for rank in range(world):

@@ -182,7 +182,7 @@ def test_global_dice_module_world1(rccl_world1):
     assert rel_l2(xb.grad, xa.grad) < 1e-7
 
 
-def _run_bench(extra_args, env_extra, timeout=600):
+def _run_bench(extra_args, env_extra, timeout=600, no_extra=True):
     import json
     import subprocess
     import sys
@@ -193,7 +193,8 @@ def _run_bench(extra_args, env_extra, timeout=600):
         env.pop(k, None)       # the rccl_world1 fixture of this module exports a rendezvous of its own
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extra"] + extra_args, env=env, capture_output=True, text=True, timeout=timeout)
+                        "--no-cpu-baseline"] + (["--no-extra"] if no_extra else []) + extra_args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -211,6 +212,30 @@ def test_bench_launches_its_own_ranks(algo):
     assert cfg["global_batch"] == 4 and len(cfg["ranks"]) == 2 and {r["rank"] for r in cfg["ranks"]} == {0, 1}
     assert cfg["ranks"][0]["pid"] != cfg["ranks"][1]["pid"]
     assert line["value"] > 0 and line["scaling"] == "weak" and all(v == v for v in line["loss_per_timed_step"])
+
+
+def test_bench_line_makes_a_multi_gpu_run_diagnosable():
+    """the ONE JSON line of an N > 1 run carries what a reader needs to explain it without the builder in
+    the loop -- the collective library's version, the communication-related environment in effect, per-bucket exchange times
+    (events on the communication stream), the EXPOSED communication per step (how long the training stream waited in
+    finish()) and, under `extra`, the same step timed with each of the three exchange algorithms.  Rehearsed with two ranks
+    sharing this box's GPU over gloo (the first RCCL run between devices is the driver's)."""
+    line = _run_bench(["--gpus", "2", "--dp-algo", "rs_ag"], {"HP_DIST_BACKEND": "gloo", "HP_SHARE_GPU": "1", "NCCL_DEBUG": "WARN"},
+                      no_extra=False)
+    cfg = line["config"]
+    lib = cfg["collective_library"]
+    assert lib["backend"] == "gloo" and lib["torch"] and "rccl" in lib
+    assert cfg["comm_env"]["NCCL_DEBUG"] == "WARN" and cfg["comm_env"]["HP_DIST_BACKEND"] == "gloo"
+    assert any(k.startswith("HSA_") for k in cfg["comm_env"])          # HSA_ENABLE_IPC_MODE_LEGACY, set by bench.py itself
+    tm = cfg["dp_timing"]
+    assert tm["algo"] == "rs_ag" and tm["steps_timed"] == 2 and len(tm["bucket_mb"]) == len(tm["bucket_exchange_ms"]) >= 1
+    assert all(v is not None and v > 0 for v in tm["bucket_exchange_ms"])
+    assert tm["exposed_ms_per_step"] is not None and 0 <= tm["exposed_ms_per_step"] <= line["ms_per_step"]
+    assert abs(tm["exchange_ms_per_step"] - sum(tm["bucket_exchange_ms"])) < 1e-2
+    ab = line["extra"]["dp_algo_ab"]
+    assert set(ab) == {"all_reduce", "rs_ag", "a2a"}
+    for v in ab.values():
+        assert v["ms_per_step"] > 0 and v["exchange_ms_per_step"] > 0 and v["exposed_ms_per_step"] is not None
 
 
 def test_bench_forced_reducer_on_one_rank_prints_its_line():

@@ -108,16 +108,15 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
 @pytest.mark.gpu
 def test_bf16_storage_mode_trains_like_fp32():
     """BASELINE configs[2]'s per-GPU arithmetic (`bf16s`: bf16 matrix cores, bf16 activations / activation gradients in HBM
-    in the regressor, bf16 operands in the U-Net's convolutions; fp32 LCT, statistics, weights and optimizer) against the
-    fp32 mode as TRAINING, not as one step: twenty Adam steps on one fixed 128^3 batch from the same initialisation
-    (reference init, seed 410).  fp32 falls 21058 -> 13330, monotone.  The bf16s curve is noisier -- the randomly
-    initialised network amplifies the 2^-9 rounding of every activation (the two FORWARD losses already differ by 5.7 % at
-    step 1) -- and, the split-K weight gradients summing with atomics, not identical run to run.  Measured over six runs per
-    variant (tools/dbg/bf16s_curves.py, gpurun_out/r3/curves_*.log), final loss above fp32's: +0.8 .. +7.3 % with an fp32
-    U-Net (MODEL.DCONV_PRECISION = 'fp32'), +1.5 .. +20 % with the bf16 U-Net that `bf16s` selects (mean +11 %; the same with
-    its weight gradients kept exact: it is the forward / data-gradient rounding inside the GroupNorm'd U-Net); single steps
-    up to 29 % off the fp32 curve.  Bars (from that spread): both fall by > 20 %; the bf16s curve never strays more than
-    40 % from the fp32 one; its best loss of the last five steps is within 25 % of fp32's and its last loss within 30 %."""
+    in the regressor; fp32 LCT, U-Net, statistics, weights and optimizer) against the fp32 mode as TRAINING, not as one step:
+    twenty Adam steps on one fixed 128^3 batch from the same initialisation (reference init), three seeds.  fp32 falls
+    21058 -> 13330 (seed 410), monotone.  The bf16s curve is noisier -- the randomly initialised network amplifies the 2^-9
+    rounding of every activation (the two FORWARD losses already differ by 5.7 % at step 1) -- and, the split-K weight
+    gradients summing with atomics, not identical run to run: over six runs its final loss lay +0.8 .. +7.3 % above fp32's
+    (tools/dbg/bf16s_curves.py, gpurun_out/r3/curves_*.log; the bf16-operand U-Net that round 3 selected by default ended
+    +1.5 .. +20 % above and is opt-in now).  Bars: every seed falls by > 20 % in both modes and ends within
+    25 % of fp32's final loss, no step strays more than 40 % from the fp32 curve, and the best of the three seeds ends within
+    10 %."""
     from hiddenpose_amd import testing as hpt
     from hiddenpose_amd.config import make_cfg
     from hiddenpose_amd.NlosPose import NlosPose
@@ -126,23 +125,28 @@ def test_bf16_storage_mode_trains_like_fp32():
     meas = hpt.synthetic_meas(2, 128, 128, "transient", seed=1).cuda()
     vol = hpt.synthetic_vol(2, 128, 128, seed=2).cuda()
     joints = hpt.synthetic_joints(2, 64, seed=3).cuda()
-    curves = {}
-    for prec in ("fp32", "bf16s"):
-        seed_everything(410)
-        cfg = make_cfg(128, 128, conv_precision=prec)
-        model = NlosPose(cfg).cuda().train()
-        criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
-        curves[prec] = [float(train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints)[0]) for _ in range(20)]
-        del model, optimizer
-        torch.cuda.empty_cache()
-    a, b = np.array(curves["fp32"]), np.array(curves["bf16s"])
-    print("fp32 :", " ".join(f"{v:.4g}" for v in a))
-    print("bf16s:", " ".join(f"{v:.4g}" for v in b))
-    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
-    assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]
-    assert np.abs(b / a - 1).max() < 0.40, (a, b)
-    assert abs(b[-5:].min() / a[-5:].min() - 1) < 0.25
-    assert abs(b[-1] / a[-1] - 1) < 0.30
+    finals = []
+    for seed in (410, 411, 412):
+        curves = {}
+        for prec in ("fp32", "bf16s"):
+            seed_everything(seed)
+            cfg = make_cfg(128, 128, conv_precision=prec)
+            model = NlosPose(cfg).cuda().train()
+            assert model.dconv_precision == "fp32"
+            criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+            curves[prec] = [float(train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints)[0]) for _ in range(20)]
+            del model, optimizer
+            torch.cuda.empty_cache()
+        a, b = np.array(curves["fp32"]), np.array(curves["bf16s"])
+        print(f"seed {seed} fp32 :", " ".join(f"{v:.4g}" for v in a))
+        print(f"seed {seed} bf16s:", " ".join(f"{v:.4g}" for v in b))
+        assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+        assert a[-1] < 0.8 * a[0] and b[-1] < 0.8 * b[0]
+        assert np.abs(b / a - 1).max() < 0.40, (a, b)
+        assert abs(b[-1] / a[-1] - 1) < 0.25
+        finals.append(abs(b[-1] / a[-1] - 1))
+    print("final loss of bf16s relative to fp32, per seed:", " ".join(f"{v:+.3f}" for v in finals))
+    assert min(finals) < 0.10, finals
 
 
 @pytest.mark.gpu

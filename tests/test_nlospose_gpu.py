@@ -328,15 +328,17 @@ def test_train_step_batch4_vs_oracle():
 
 def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
     """BASELINE.json configs[2] in full (MODEL.CONV_PRECISION='bf16s': bf16 matrix cores AND bf16 activation storage in
-    the regressor, bf16 operands in the U-Net's multi-channel convolutions (MODEL.DCONV_PRECISION 'auto' -> 'bf16'); LCT,
-    norms, soft-argmax, losses, statistics, weights, U-Net tensors fp32): eval forward against the fp32
-    reference goldens at BF16_TOL, and one 128^3 train step (smooth filler) against the fp32 mode -- losses, heat-maps and
-    the direction of ten named gradients -- and against the same mode with an fp32 U-Net (MODEL.DCONV_PRECISION='fp32')."""
+    the regressor; LCT, U-Net, norms, soft-argmax, losses, statistics, weights fp32 -- MODEL.DCONV_PRECISION 'auto' is
+    'fp32' since round 4), and the opt-in bf16-operand U-Net on top of it (MODEL.DCONV_PRECISION='bf16'): eval forward
+    against the fp32 reference goldens at BF16_TOL, and one 128^3 train step (smooth filler) against the fp32 mode --
+    losses, heat-maps and the direction of ten named gradients."""
     BF16_TOL = 3e-2
     for T, N, name in ((32, 32, "e2e_T32_N32.npz"), (128, 128, "e2e_T128_N128.npz")):
         g = golden(name)
         cfg = make_cfg(T, N, conv_precision="bf16s")
+        cfg.MODEL.DCONV_PRECISION = "bf16"          # the loosest combination: bf16 U-Net operands as well
         model = NlosPose(cfg)
+        assert model.dconv_precision == "bf16"
         hpt.fill_module(model)
         model = model.cuda().eval()
         B = 2 if T == 32 else 1
@@ -363,12 +365,12 @@ def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
     vol = hpt.synthetic_vol(B, T, N).cuda()
     joints = hpt.synthetic_joints(B, T // 2).cuda()
     out = {}
-    for mode in ("fp32", "bf16s", "bf16s+fp32unet"):
+    for mode in ("fp32", "bf16s+bf16unet", "bf16s"):
         cfg = make_cfg(T, N, conv_precision=mode.split("+")[0])
-        if mode.endswith("fp32unet"):
-            cfg.MODEL.DCONV_PRECISION = "fp32"
+        if mode.endswith("bf16unet"):
+            cfg.MODEL.DCONV_PRECISION = "bf16"
         model = NlosPose(cfg)
-        assert model.dconv_precision == ("bf16" if mode == "bf16s" else "fp32")
+        assert model.dconv_precision == ("bf16" if mode.endswith("bf16unet") else "fp32")   # 'auto' = exact U-Net in every mode
         # the SMOOTH filler (ReLU decisions far from rounding noise): with the default one this train-mode network amplifies
         # a 1e-2 perturbation of the regressor's input (the bf16 U-Net) until gradients decorrelate, which says nothing
         hpt.fill_module(model, smooth=True)
@@ -380,8 +382,9 @@ def test_bf16_storage_mode_vs_reference_golden_and_bf16_mode(golden, capsys):
         out[mode] = (jl.item(), vl.item(), heat.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
         del model, optimizer, loss, heat, refine
         torch.cuda.empty_cache()
-    (jl0, vl0, h0, g0), (jl1, vl1, h1, g1) = out["fp32"], out["bf16s"]
-    assert abs(out["bf16s+fp32unet"][1] / vl0 - 1) < 1e-6   # with an fp32 U-Net that branch does not touch a bf16 value
+    (jl0, vl0, h0, g0), (jl1, vl1, h1, g1) = out["fp32"], out["bf16s+bf16unet"]
+    assert abs(out["bf16s"][1] / vl0 - 1) < 1e-6   # default bf16s: the U-Net branch does not touch a bf16 value
+    assert abs(out["bf16s"][0] / jl0 - 1) < 5e-3 and rel_l2(out["bf16s"][2], h0) < 2e-2
     cos = {}
     for k in ["feature_extraction.weights", "autoencoder.conv.double_conv.0.weight", "pose_net.conv1.weight",
               "pose_net.layer1.0.conv2.weight", "pose_net.layer2.0.conv2.weight", "pose_net.layer3.2.conv1.weight",
@@ -568,4 +571,7 @@ def test_train_step_benchmark_cube_512_batch2_vs_reference_golden(golden, capsys
             # 5.9e-3; against float64 (batch 1, above) ours are 3.9e-4, 1.2e-3, 6.2e-4 from the truth
             assert e < (0.15 if k.endswith("out.conv.bias") else 3e-2), (k, e)
             continue
-        assert e < max(1e-3, 3.0 * float(g1["spread_" + k])), (k, e, float(g1["spread_" + k]))
+        regressor = k.startswith("pose_net.") and k != "pose_net.bn1.weight"
+        # (the stem's BatchNorm weight and the U-Net: 2.5e-3 is what float32 summation order alone moves them by -- against
+        # float64 ours measure 7.8e-4 .. 1.5e-3 at this volume, batch 1)
+        assert e < max(1e-3 if regressor else 2.5e-3, 3.0 * float(g1["spread_" + k])), (k, e, float(g1["spread_" + k]))
