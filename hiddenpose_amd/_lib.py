@@ -125,6 +125,9 @@ SIGNATURES = {
 }
 
 
+STATS_SLOTS = 32   # HP_STATS_SLOTS (include/hiddenpose_hip.h): partial statistics vectors of hp_conv3d_forward
+
+
 class ConvDesc(C.Structure):
     """Mirror of `hp_conv_desc` (include/hiddenpose_hip.h)."""
     _fields_ = [(n, C.c_int) for n in ("B", "Di", "Hi", "Wi", "Cin", "Cout", "k", "stride", "pad", "transposed", "precision", "io")]

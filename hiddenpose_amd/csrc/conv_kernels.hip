@@ -926,8 +926,10 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           s += (double)red[(w * BN + tid) * 2 + 0];
           q += (double)red[(w * BN + tid) * 2 + 1];
         }
-        atomicAdd(stats + n, s);
-        atomicAdd(stats + g.Nout + n, q);
+        // (the launch index, not the M tile: with the XCD slab order the tiles in flight differ by multiples of the slab length)
+        double* const slot = stats + (size_t)((blockIdx.x + blockIdx.z) & (HP_STATS_SLOTS - 1)) * 2 * g.Nout;   // see hp_conv3d_forward
+        atomicAdd(slot + n, s);
+        atomicAdd(slot + g.Nout + n, q);
       }
     }
   }
@@ -2365,8 +2367,9 @@ __global__ __launch_bounds__(512) void k_stem_fwd_bf16(const float* __restrict__
         sv += (double)red[(w * 64 + tid) * 2 + 0];
         qv += (double)red[(w * 64 + tid) * 2 + 1];
       }
-      atomicAdd(stats + tid, sv);
-      atomicAdd(stats + 64 + tid, qv);
+      double* const slot = stats + (size_t)(blockIdx.x & (HP_STATS_SLOTS - 1)) * 128;
+      atomicAdd(slot + tid, sv);
+      atomicAdd(slot + 64 + tid, qv);
     }
   }
 }
@@ -2524,8 +2527,9 @@ __global__ __launch_bounds__(256) void k_stem_fwd_mfma(const float* __restrict__
   if (stats && lane < 32) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      atomicAdd(stats + 32 * hh + lane, (double)ssum[hh]);
-      atomicAdd(stats + 64 + 32 * hh + lane, (double)ssq[hh]);
+      double* const slot = stats + (size_t)(blockIdx.x & (HP_STATS_SLOTS - 1)) * 128;
+      atomicAdd(slot + 32 * hh + lane, (double)ssum[hh]);
+      atomicAdd(slot + 64 + 32 * hh + lane, (double)ssq[hh]);
     }
   }
 }
@@ -2853,7 +2857,7 @@ extern "C" int hp_conv3d_forward(const hp_conv_desc* d, const void* x, const flo
   HP_REQUIRE(!p.fwd.wh || (p.fwd.xh && p.planes == 1 && !p.stem && d->Cin % 64 == 0),
              "hp_conv3d_forward: bf16 packed weights go with a bf16 input, HP_PRECISION_BF16 and Cin %% 64 == 0");
   hipStream_t st = (hipStream_t)stream;
-  if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout, st));
+  if (stats) HP_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * d->Cout * HP_STATS_SLOTS, st));
   if (p.stem && p.planes == 1 && d->Cout == 64 && !bias && !p.fwd.yh) {
     // single-plane bf16 arithmetic: persistent workgroups (one per CU: 100 KB of LDS), 16 x 4 x 8 voxel tiles
     const int pz = (d->Di + SFH_TZ - 1) / SFH_TZ, py = (d->Hi + SFH_TY - 1) / SFH_TY, px = (d->Wi + SFH_TX - 1) / SFH_TX;

@@ -75,15 +75,20 @@ __device__ __forceinline__ float4 f4_dz(float4 g, float4 v, float4 a, float4 b, 
   return make_float4(a.x * g.x + b.x * v.x + k.x, a.y * g.y + b.y * v.y + k.y, a.z * g.z + b.z * v.z + k.z, a.w * g.w + b.w * v.w + k.w);
 }
 
-// stats[0:C] = sum, stats[C:2C] = sum of squares (fp64) over M rows
+// stats[s][0:C] = sum, stats[s][C:2C] = sum of squares (fp64) over the rows of slot s
 __global__ void k_bn_finalize(const double* __restrict__ stats, long M, int C, float eps, float momentum,
                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                               float* __restrict__ running_var, long long* __restrict__ num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;  // BatchNorm3d's counter, in the same launch
   if (c >= C) return;
-  const double m = stats[c] / (double)M;
-  double var = stats[C + c] / (double)M - m * m;
+  double s1 = 0.0, s2 = 0.0;   // the convolution epilogue's HP_STATS_SLOTS partial vectors (include/hiddenpose_hip.h)
+  for (int sl = 0; sl < HP_STATS_SLOTS; ++sl) {
+    s1 += stats[(size_t)sl * 2 * C + c];
+    s2 += stats[(size_t)sl * 2 * C + C + c];
+  }
+  const double m = s1 / (double)M;
+  double var = s2 / (double)M - m * m;
   if (var < 0) var = 0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));

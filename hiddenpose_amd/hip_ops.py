@@ -850,7 +850,7 @@ class _ConvBnAct(torch.autograd.Function):
             z = torch.empty(desc.B, do, ho, wo, cout, dtype=_BF if act else torch.float32, device=x.device)
             M = z.numel() // cout
             train = bn.training
-            stats = torch.empty(2 * cout, dtype=torch.float64, device=x.device) if train else None
+            stats = torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device=x.device) if train else None
             desc.io = (HP_IO_X if _h(x) else 0) | (HP_IO_W if wh else 0) | (HP_IO_Y if act else 0)
             _lib.check(L.hp_conv3d_forward(_C.byref(desc), x.data_ptr(), wf.data_ptr(), None, z.data_ptr(),
                                            _lib.ptr(stats), st), "hp_conv3d_forward")
@@ -1066,7 +1066,7 @@ class _StemConvBnReluPool(torch.autograd.Function):
             z = torch.empty(b, d, h, wd_, cout, dtype=torch.float32, device=x.device)
             M = z.numel() // cout
             train = bn.training
-            stats = torch.empty(2 * cout, dtype=torch.float64, device=x.device) if train else None
+            stats = torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device=x.device) if train else None
             _lib.check(L.hp_conv3d_forward(_C.byref(desc), x.data_ptr(), wf.data_ptr(), None, z.data_ptr(), _lib.ptr(stats), st),
                        "hp_conv3d_forward")
             mean = torch.empty(cout, dtype=torch.float32, device=x.device)

@@ -151,8 +151,13 @@ typedef struct hp_conv_desc {
 size_t hp_conv3d_packed_weight_elems(const hp_conv_desc* d);
 int hp_conv3d_pack_weight(const hp_conv_desc* d, const float* w_torch, void* w_fwd, void* w_dgrad, void* stream);
 int hp_conv3d_unpack_wgrad(const hp_conv_desc* d, const float* dw_packed, float* dw_torch, void* stream);
-/* y = conv(x) [+ bias]; if stats != NULL it receives per-channel sum and sum of squares of y
- * (2*Cout doubles, zeroed by the call) for train-mode BatchNorm. */
+/* y = conv(x) [+ bias]; if stats != NULL it receives per-channel sums and sums of squares of y for train-mode BatchNorm
+ * as HP_STATS_SLOTS partial vectors: stats[s][0 .. Cout) sums, stats[s][Cout .. 2 Cout) sums of squares over the workgroups
+ * whose launch index % HP_STATS_SLOTS == s (HP_STATS_SLOTS * 2 * Cout doubles, zeroed by the call; hp_bn_train_finalize* adds
+ * the slots).  Why slots: every workgroup ends with one fp64 atomic per column and statistic, and atomics on ONE address
+ * serialise at ~16 ns each -- 32768 M tiles per address made the 64-channel 1^3 layers of layer 1 take 0.73 instead of
+ * 0.21 ms (bf16 storage) / 0.88 instead of 0.49 ms (fp32) at the headline shape. */
+#define HP_STATS_SLOTS 32
 int hp_conv3d_forward(const hp_conv_desc* d, const void* x, const float* w_fwd, const float* bias, void* y,
                       double* stats, void* stream);
 /* dx = conv^T(dy) [+ addend]: `addend` (same shape as dx, may be NULL) lets a second gradient contribution to the
@@ -181,6 +186,7 @@ int hp_conv3d_backward_weight_split(const hp_conv_desc* d, long* msplit, long* c
 #define HP_BN_DY_BF16 2  /* backward: the incoming gradient dy */
 #define HP_BN_DZ_BF16 4  /* backward: the outgoing gradients dz (and g_out) */
 #define HP_BN_Z_BF16 8   /* the raw convolution output z (and, in hp_bn_apply_res_bn, the raw shortcut output) */
+/* stats: the HP_STATS_SLOTS x 2C partial sums of hp_conv3d_forward (see there). */
 int hp_bn_train_finalize(const double* stats, long M, int C, float eps, float momentum, float* mean, float* rstd,
                          float* running_mean, float* running_var, void* stream);
 /* Same, and BatchNorm3d's `num_batches_tracked` (int64, device) is incremented by the same launch (may be NULL). */

@@ -84,8 +84,9 @@ def test_conv_forward_and_gradients(name, cin, cout, k, s, p, tr, dims, precisio
     do, ho, wo = ops._out_dims(desc)
     assert (do, ho, wo) == tuple(ref.shape[2:])
     y = torch.empty(B, do, ho, wo, cout, device="cuda")
-    stats = torch.empty(2 * cout, dtype=torch.float64, device="cuda")
+    stats = torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device="cuda")
     _lib.check(L.hp_conv3d_forward(C.byref(desc), xc.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st), "fwd")
+    stats = stats.view(_lib.STATS_SLOTS, 2 * cout).sum(0)      # the epilogue's partial vectors (HP_STATS_SLOTS)
     assert rel_l2(ncdhw(y), ref) < tol_f
     refcl = cl(ref.detach())
     assert rel_l2(stats[:cout], refcl.reshape(-1, cout).sum(0)) < 10 * tol_f
@@ -145,7 +146,7 @@ def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch
         # forward at the same odd extents (depth 22: the 16-plane tiles of the bf16-mode stem kernel end in a partial tile)
         wf, _ = ops._pack(desc, w.cuda(), True, False)
         y = torch.empty(B, D, H, W, 64, device="cuda")
-        stats = torch.empty(128, dtype=torch.float64, device="cuda")
+        stats = torch.empty(_lib.STATS_SLOTS * 128, dtype=torch.float64, device="cuda")
         _lib.check(_lib.lib().hp_conv3d_forward(C.byref(desc), xc.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(),
                                                 ops._stream(xc)), "fwd")
         dx, dw = ops._conv_grads(desc, xc, w.cuda(), cl(gy).cuda(), True)
@@ -153,6 +154,7 @@ def test_stem_data_gradient_walks_patches_along_z(precision, zsplit, monkeypatch
         ops.set_conv_precision(prev)
     assert rel_l2(ncdhw(y), ref) < 2e-6
     refcl = cl(ref.detach())
+    stats = stats.view(_lib.STATS_SLOTS, 128).sum(0)
     assert rel_l2(stats[:64], refcl.reshape(-1, 64).sum(0)) < 2e-5 and rel_l2(stats[64:], (refcl.reshape(-1, 64) ** 2).sum(0)) < 2e-5
     assert rel_l2(ncdhw(dx), xd.grad) < 5e-6
     assert rel_l2(dw, wd.grad) < 5e-6
@@ -454,14 +456,14 @@ def test_conv_bf16_storage(name, cin, cout, k, s, p, tr, dims):
     wf, _ = ops._pack(desc, wc, True, False, wh)
     assert wf.dtype == (torch.bfloat16 if wh else torch.float32)
     do, ho, wo = ops._out_dims(desc)
-    stats = torch.empty(2 * cout, dtype=torch.float64, device="cuda")
+    stats = torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device="cuda")
     for yh in (False, True):
         y = torch.empty(B, do, ho, wo, cout, device="cuda", dtype=torch.bfloat16 if yh else torch.float32)
         desc.io = ops.HP_IO_X | (ops.HP_IO_W if wh else 0) | (ops.HP_IO_Y if yh else 0)
         _lib.check(L.hp_conv3d_forward(C.byref(desc), xh.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st), "fwd")
         assert rel_l2(ncdhw(y.float()), ref) < (4e-3 if yh else 2e-6)
         refcl = cl(ref.detach())
-        assert rel_l2(stats[:cout], refcl.reshape(-1, cout).sum(0)) < 2e-5      # statistics come from the fp32 accumulators
+        assert rel_l2(stats.view(_lib.STATS_SLOTS, 2 * cout).sum(0)[:cout], refcl.reshape(-1, cout).sum(0)) < 2e-5   # from the fp32 accumulators
     dzh = cl(gy).cuda().bfloat16()
     dx, dw = ops._conv_grads(desc, xh, wc, dzh, True)
     assert dx.dtype == torch.bfloat16 and dw.dtype == torch.float32

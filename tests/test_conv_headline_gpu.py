@@ -168,7 +168,7 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
     y = torch.empty(B, *dout, cout, device=dev)
     head = name == "head"
     bias = torch.randn(cout, device=dev) if head else None
-    stats = None if head else torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    stats = None if head else torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device=dev)
     _lib.check(L.hp_conv3d_forward(C.byref(desc), x.data_ptr(), wf.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.ptr(stats), st),
                "hp_conv3d_forward")
     special = _marks(cout * 4, Mo) + _to_rowspace(_marks(cin * 4, Mi), din, dout)
@@ -183,7 +183,7 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
         ym = y.reshape(B, -1, cout)
         s1 = sum(ym[b].sum(0, dtype=torch.float64) for b in range(B))
         s2 = sum((ym[b].double() ** 2).sum(0) for b in range(B))
-        got_s = stats.cpu().numpy()
+        got_s = stats.view(_lib.STATS_SLOTS, 2 * cout).sum(0).cpu().numpy()     # the epilogue's partial vectors (HP_STATS_SLOTS)
         # tile sums are fp32 before they meet in fp64 atomics: |error of the sum| ~ 2^-24 sqrt(rows per tile) rms(y) per tile
         np.testing.assert_allclose(got_s[cout:], s2.cpu().numpy(), rtol=1e-6, err_msg=f"{name} statistics epilogue (sum of squares)")
         np.testing.assert_allclose(got_s[:cout], s1.cpu().numpy(), rtol=0, atol=1e-6 * float(s2.max().sqrt()),

@@ -80,7 +80,7 @@ for name, cin, cout, k, s, p, tr, d in layers():
         t = timeit(lambda: L.hp_conv3d_forward(C.byref(desc), x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), None, st))
         res.append(f"fwd {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
         if os.environ.get("HP_TIME_STATS"):   # the same with the BatchNorm statistics epilogue (fp64 atomics per block and column)
-            stats = torch.empty(2 * cout, dtype=torch.float64, device="cuda")
+            stats = torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device="cuda")
             t = timeit(lambda: L.hp_conv3d_forward(C.byref(desc), x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), stats.data_ptr(), st))
             res.append(f"fwd+stats {t*1e3:8.3f} ms {flops/t/1e12:6.1f} TF")
     if "dgrad" in which:
