@@ -61,6 +61,12 @@ struct IgemmGeom {
                            //    their gates; Y has Nout / 2 columns and receives value * gelu(gate)
   int slab;                // > 0: M tiles per XCD -- XCD k (workgroup b runs on XCD b % 8) walks M tiles k * slab .. (k + 1) * slab - 1
   long welems;             // elements of the packed weight image this geometry reads (descriptor extents)
+  // BNS instantiations (hp_conv3d_backward_data_bnsums): the written tensor is the output gradient dy_a of the BatchNorm unit
+  // that produced this convolution's input; its raw output z_a and parameters, and where the two backward sums go
+  const float* bn_z;
+  const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
+  double* bn_sums;         // HP_STATS_SLOTS x 2 x Nout doubles: sum g, sum g * zhat with g = dy_a (.) [y_a > 0]
+  int bn_relu;
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -197,7 +203,7 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
 // returns 0.  Why it matters: tools/micro/mfma_coexec.hip -- while one wave streams fp32 MFMAs, vector-ALU, vector-memory
 // and LDS-read instructions of the OTHER waves of that SIMD do not issue at all, i.e. every such instruction of the K loop
 // is paid in matrix-pipe time whichever wave executes it.
-template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false>
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false, bool BNS = false>
 __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, void* __restrict__ Y,
                                               double* __restrict__ stats, const void* __restrict__ addend,
@@ -686,6 +692,22 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     const unsigned vo = (unsigned)((r_l * g.Nout + 4 * q_l) * 4);
     float4 bv = make_float4(0, 0, 0, 0);
     if (fast && bias) bv = *(const float4*)(bias + n0 + 4 * q_l);
+    // BNS: the tile just computed IS dy_a of the BatchNorm unit a in front of this convolution (this launch is the data gradient
+    // of the only consumer of y_a): its backward sums  s = sum g,  d = sum g * zhat  (g = dy_a (.) [y_a > 0], zhat = (z_a - mean)
+    // * rstd; the expressions are k_bn_bwd_reduce's) are taken here, from the tile in hand and ONE read of the z_a tile, instead
+    // of by a separate pass over dy_a and z_a.  Host-checked: every tile of a BNS launch is whole (the `fast` path).
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t zrs = yrs;
+    [[maybe_unused]] float4 b_m = make_float4(0, 0, 0, 0), b_r = b_m, b_sc = b_m, b_sh = b_m, b_s = b_m, b_d = b_m;
+    if constexpr (BNS) {
+      zrs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bn_z + tile_el), 0, y_rec, 0x00020000);
+      b_m = *(const float4*)(g.bn_mean + n0 + 4 * q_l);
+      b_r = *(const float4*)(g.bn_rstd + n0 + 4 * q_l);
+      if (g.bn_relu) {
+        const float4 ga = *(const float4*)(g.bn_gamma + n0 + 4 * q_l), be = *(const float4*)(g.bn_beta + n0 + 4 * q_l);
+        b_sc = make_float4(b_r.x * ga.x, b_r.y * ga.y, b_r.z * ga.z, b_r.w * ga.w);
+        b_sh = make_float4(be.x - b_m.x * b_sc.x, be.y - b_m.y * b_sc.y, be.z - b_m.z * b_sc.z, be.w - b_m.w * b_sc.w);
+      }
+    }
 #pragma unroll
     for (int h = 0; h < C::TM; ++h) {
       __syncthreads();
@@ -702,6 +724,15 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
       constexpr int K2 = (64 * Q) / CT;
       float4 avb[K2];
       unsigned mkb[K2];
+      [[maybe_unused]] float4 zvb[BNS ? K2 : 1];
+      if constexpr (BNS) {
+#pragma unroll
+        for (int k2 = 0; k2 < K2; ++k2) {
+          const int rowc = k2 * RPK;
+          const unsigned so = (unsigned)(((rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31)) * g.Nout * 4);
+          zvb[k2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(zrs, vo, so, 0));
+        }
+      }
       if (fast && addend) {
 #pragma unroll
         for (int k2 = 0; k2 < K2; ++k2) {
@@ -763,6 +794,21 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           }
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, vo, so, 0);
+          if constexpr (BNS) {
+            const float4 zz = zvb[k2];
+            float4 gg = v;
+            if (g.bn_relu) {
+              gg.x = fmaf(zz.x, b_sc.x, b_sh.x) > 0.f ? v.x : 0.f;
+              gg.y = fmaf(zz.y, b_sc.y, b_sh.y) > 0.f ? v.y : 0.f;
+              gg.z = fmaf(zz.z, b_sc.z, b_sh.z) > 0.f ? v.z : 0.f;
+              gg.w = fmaf(zz.w, b_sc.w, b_sh.w) > 0.f ? v.w : 0.f;
+            }
+            b_s.x += gg.x; b_s.y += gg.y; b_s.z += gg.z; b_s.w += gg.w;
+            b_d.x += gg.x * (zz.x - b_m.x) * b_r.x;
+            b_d.y += gg.y * (zz.y - b_m.y) * b_r.y;
+            b_d.z += gg.z * (zz.z - b_m.z) * b_r.z;
+            b_d.w += gg.w * (zz.w - b_m.w) * b_r.w;
+          }
         }
         continue;
       }
@@ -870,6 +916,28 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           for (int e = 0; e < 4; ++e)
             if (n + e < g.Nout) st_y1(yo + e, vv[e] + (bias ? bias[n + e] : 0.f) + (addend ? ld_a1(yo + e) : 0.f));
         }
+      }
+    }
+    if constexpr (BNS) {
+      // column sums over the tile's rows: the RPK threads that share a column quad meet in the (now free) staging arena, then
+      // one fp64 atomic per column and statistic into this workgroup's slot (HP_STATS_SLOTS, as the forward statistics)
+      __syncthreads();
+      float4* const part = (float4*)smem;        // [RPK][Q][2]
+      part[(r_l * Q + q_l) * 2 + 0] = b_s;
+      part[(r_l * Q + q_l) * 2 + 1] = b_d;
+      __syncthreads();
+      if (tid < Q) {
+        float4 ss = part[tid * 2], dd = part[tid * 2 + 1];
+#pragma unroll
+        for (int rr = 1; rr < RPK; ++rr) {
+          const float4 a = part[(rr * Q + tid) * 2], b = part[(rr * Q + tid) * 2 + 1];
+          ss.x += a.x; ss.y += a.y; ss.z += a.z; ss.w += a.w;
+          dd.x += b.x; dd.y += b.y; dd.z += b.z; dd.w += b.w;
+        }
+        double* const slot = g.bn_sums + (size_t)((blockIdx.x + blockIdx.z) & (HP_STATS_SLOTS - 1)) * 2 * g.Nout + n0 + 4 * tid;
+        atomicAdd(slot + 0, (double)ss.x); atomicAdd(slot + 1, (double)ss.y); atomicAdd(slot + 2, (double)ss.z); atomicAdd(slot + 3, (double)ss.w);
+        atomicAdd(slot + g.Nout + 0, (double)dd.x); atomicAdd(slot + g.Nout + 1, (double)dd.y);
+        atomicAdd(slot + g.Nout + 2, (double)dd.z); atomicAdd(slot + g.Nout + 3, (double)dd.w);
       }
     }
   } else {
@@ -2931,6 +2999,66 @@ extern "C" int hp_linear_geglu_forward(const float* x, const float* w, const flo
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;
+}
+
+// Data gradient whose output is the incoming gradient of the BatchNorm unit in front of the convolution: the same exact-fp32
+// whole-tile kernels with the BNS epilogue (see k_igemm).  Returns false when the geometry is not one they cover.
+static bool launch_igemm_bns(const IgemmGeom& g, const void* X, const float* W, void* Y, const void* addend,
+                             const unsigned char* amask, hipStream_t st) {
+  const bool dense_out = g.os == 1 && g.gd == g.Do && g.gh == g.Ho && g.gw == g.Wo;
+  if (g.mode != MODE_CONV || !dense_out || g.M % BM != 0 || g.Nout <= 32 || g.Nout % (g.Nout > 64 ? 128 : 64) != 0 || g.xh || g.yh ||
+      g.wh || g.ah)
+    return false;
+  const unsigned mt = (unsigned)(g.M / BM);
+  static const bool bl_on = !(getenv("HP_IGEMM_BL") && atoi(getenv("HP_IGEMM_BL")) == 0);
+  static const bool slab_on = !(getenv("HP_IGEMM_SLAB") && atoi(getenv("HP_IGEMM_SLAB")) == 0);
+  const bool bl = bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 < (1l << 31);
+  IgemmGeom gg = g;
+  gg.slab = slab_on ? (int)((mt + 7) / 8) : 0;
+  if (g.Nout <= 64) {   // one N tile of 64 columns (launch_igemm_bn's first two branches)
+    const dim3 grid = gg.slab ? dim3((mt + 7) / 8 * 8, 1, 1) : dim3(mt, 1, 1);
+    if (bl) hipLaunchKernelGGL((k_igemm<64, false, false, 0, false, false, true, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
+    else hipLaunchKernelGGL((k_igemm<64, false, false, 0, false, false, false, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
+    return true;
+  }
+  const unsigned tn = (unsigned)(g.Nout / 128);
+  gg.tn = tn > 1 ? (int)tn : 0;
+  const dim3 grid = (tn > 1 || gg.slab) ? dim3((mt + 7) / 8 * 8 * (tn > 1 ? tn : 1), 1, 1) : dim3(mt, 1, 1);
+  if (bl) hipLaunchKernelGGL((k_igemm<128, false, false, 0, false, false, true, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
+  else hipLaunchKernelGGL((k_igemm<128, false, false, 0, false, false, false, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
+  return true;
+}
+
+extern "C" int hp_conv3d_backward_data_bnsums(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx, const void* addend,
+                                              const unsigned char* addend_mask, const float* z, const float* mean,
+                                              const float* rstd, const float* gamma, const float* beta, int relu, double* sums,
+                                              int* fused, void* stream) {
+  HP_REQUIRE(d && dy && w_dgrad && dx && z && mean && rstd && sums && fused && (!relu || (gamma && beta)),
+             "hp_conv3d_backward_data_bnsums: null argument");
+  *fused = 0;
+  ConvPlan p;
+  int rc = make_plan(*d, p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.planes == 0 && !p.stem && !p.dgrad_zero_fill && d->io == 0 && p.dgrad_classes == 1 &&
+      (!addend_mask || (addend && d->Cin % 4 == 0 && d->Cin > 32))) {
+    IgemmGeom g = p.dgrad;
+    g.bn_z = z;
+    g.bn_mean = mean;
+    g.bn_rstd = rstd;
+    g.bn_gamma = gamma;
+    g.bn_beta = beta;
+    g.bn_sums = sums;
+    g.bn_relu = relu ? 1 : 0;
+    HP_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * g.Nout * HP_STATS_SLOTS, st));
+    HP_PROF("conv_igemm_dgrad", st);
+    if (launch_igemm_bns(g, dy, w_dgrad, dx, addend, addend_mask, st)) {
+      HP_CHECK_HIP(hipGetLastError());
+      *fused = 1;
+      return HP_OK;
+    }
+  }
+  return hp_conv3d_backward_data_masked(d, dy, w_dgrad, dx, addend, addend_mask, stream);
 }
 
 extern "C" int hp_conv3d_backward_data(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx,

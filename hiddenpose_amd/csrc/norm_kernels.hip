@@ -1160,6 +1160,42 @@ extern "C" int hp_bn_backward(const void* dy, const float* y, const void* z, voi
   return HP_OK;
 }
 
+__global__ void k_bn_sum_slots(const double* __restrict__ slots, double* __restrict__ red, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int sl = 0; sl < HP_STATS_SLOTS; ++sl) s += slots[(size_t)sl * n + i];
+  red[i] = s;
+}
+
+extern "C" int hp_bn_backward_presummed(const void* dy, const void* z, void* dz, long M, int C, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta_for_mask, int relu, int train,
+                                        float* dgamma, float* dbeta, const double* sums, void* workspace, int io, void* stream) {
+  const int dy_half = (io & HP_BN_DY_BF16) ? 1 : 0, dz_half = (io & HP_BN_DZ_BF16) ? 1 : 0, z_half = (io & HP_BN_Z_BF16) ? 1 : 0;
+  HP_REQUIRE(dy && z && dz && mean && rstd && gamma && sums && workspace && M > 0 && C > 0 && C % 4 == 0 && dy != dz,
+             "hp_bn_backward_presummed: bad argument");
+  HP_REQUIRE(!relu || beta_for_mask, "hp_bn_backward_presummed: relu needs beta to rebuild the mask from z");
+  hipStream_t st = (hipStream_t)stream;
+  double* red = (double*)workspace;
+  float* ca = (float*)(red + 2 * C);
+  float* cb = ca + C;
+  float* cc = cb + C;
+  const int C4 = C / 4;
+  hipLaunchKernelGGL(k_bn_sum_slots, dim3((2 * C + 127) / 128), dim3(128), 0, st, sums, red, 2 * C);
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3((C + 127) / 128), dim3(128), 0, st, red, M, C, mean, rstd, gamma, train, dgamma,
+                     dbeta, ca, cb, cc);
+  {
+    HP_PROF("bn_bwd_apply", st);
+    const long n4 = M * C4;
+    const int iom = io_mode(C4, {dy_half, z_half, dz_half});
+    HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+                  (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean, (const float4*)rstd,
+                  (const float4*)gamma, (const float4*)beta_for_mask, relu);
+  }
+  HP_CHECK_HIP(hipGetLastError());
+  return HP_OK;
+}
+
 extern "C" int hp_bn_backward_dual(const void* dy, const unsigned char* relu_mask, long M, int C, const void* z_a,
                                    void* dz_a, const float* mean_a, const float* rstd_a, const float* gamma_a, int train_a,
                                    float* dgamma_a, float* dbeta_a, const void* z_b, void* dz_b, const float* mean_b,

@@ -666,6 +666,29 @@ class ResLink:
         self.done = None     # both BatchNorm backwards in one pair of passes and leaves (dz, dgamma, dbeta) here
 
 
+class BnLink:
+    """Joins a conv + BatchNorm (+ ReLU) unit WITHOUT residual (the producer) to the one convolution that consumes its output
+    (the consumer).  The consumer's data gradient IS the producer's incoming gradient, so the consumer's data-gradient kernel
+    also takes the producer's two BatchNorm-backward sums (hp_conv3d_backward_data_bnsums, from the tile in hand and one read
+    of the producer's raw output) and leaves them here; the producer's backward then skips its reduction pass over dy and z
+    (hp_bn_backward_presummed).  Exact-fp32 tensors and whole-tile geometries only; otherwise `sums` stays None and nothing
+    changes.  HP_BN_FUSE=0 switches the hand-over off (A/B runs)."""
+    __slots__ = ("src", "sums")
+
+    def __init__(self):
+        self.src = None    # (z, mean, rstd, gamma, beta, relu) of the producer, set by its forward
+        self.sums = None   # HP_STATS_SLOTS x 2C doubles, set by the consumer's backward
+
+
+_BN_FUSE = __import__("os").environ.get("HP_BN_FUSE", "1") != "0"
+_bn_fused_calls = [0]   # data gradients that took a BatchNorm unit's sums (tests assert the path was taken where it should be)
+
+
+def bn_link():
+    """A BnLink when a backward pass may follow and the hand-over is enabled, else None."""
+    return BnLink() if (_BN_FUSE and torch.is_grad_enabled()) else None
+
+
 # Weight gradients on a second HIP stream (default since round 4; HP_WGRAD_STREAM=0 or set_wgrad_async(False) keeps
 # everything on one stream).  A weight gradient has no consumer before the optimizer (or the gradient all-reduce), so it
 # runs concurrently with the rest of backward: tails of one GEMM are filled by the other's blocks and the memory-bound
@@ -745,8 +768,9 @@ def join_side_streams():
             q.clear()            # everything queued so far is ordered before whatever the main stream does next
 
 
-def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
-    """(dx, dw) of z = conv(x, w) given dz; all channels-last, dw in the torch weight layout."""
+def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=None):
+    """(dx, dw) of z = conv(x, w) given dz; all channels-last, dw in the torch weight layout.  bn_in: the BnLink of the unit that
+    produced x (see there): its BatchNorm-backward sums are taken by the data-gradient kernel where the geometry allows."""
     L = _lib.lib()
     st = _stream(x)
     dx = None
@@ -761,7 +785,18 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None):
         # addend's own buffer (no zero-filled tensor, no copy)
         inplace = addend is not None and addend_mask is None and desc.k == 1 and desc.stride == 2 and not desc.transposed
         dx = addend if inplace else torch.empty_like(x)
-        if addend_mask is not None:
+        if bn_in is not None and bn_in.src is not None and not inplace and desc.io == 0 and desc.precision == 0 and x.dtype == torch.float32:
+            zs, ms, rs, gs, bs, relu_s = bn_in.src
+            sums = torch.empty(_lib.STATS_SLOTS * 2 * x.shape[-1], dtype=torch.float64, device=x.device)
+            fused = _C.c_int(0)
+            _lib.check(L.hp_conv3d_backward_data_bnsums(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend),
+                                                        _lib.ptr(addend_mask), zs.data_ptr(), ms.data_ptr(), rs.data_ptr(),
+                                                        gs.data_ptr(), bs.data_ptr(), 1 if relu_s else 0, sums.data_ptr(),
+                                                        _C.byref(fused), st), "hp_conv3d_backward_data_bnsums")
+            if fused.value:
+                bn_in.sums = sums
+                _bn_fused_calls[0] += 1
+        elif addend_mask is not None:
             _lib.check(L.hp_conv3d_backward_data_masked(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(),
                                                         addend.data_ptr(), addend_mask.data_ptr(), st),
                        "hp_conv3d_backward_data_masked")
@@ -832,7 +867,8 @@ class _ConvBnAct(torch.autograd.Function):
     """y = act(BN(conv(x)) [+ res]) with the BN batch statistics reduced in the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None, res_link=None):
+    def forward(ctx, x, w, gamma, beta, res, bn, k, stride, pad, transposed, relu, link_in=None, link_out=None, res_link=None,
+                bn_in=None, bn_out=None):
         L = _lib.lib()
         x = x.contiguous()
         ctx.use_epoch = _use_epoch[0]
@@ -873,6 +909,7 @@ class _ConvBnAct(torch.autograd.Function):
                 ctx.cfg = (desc, relu, train, False)
                 ctx.act = _act_bf16 or _h(x)
                 ctx.links = (link_in, link_out, res_link)
+                ctx.bn_links = (bn_in, None)
                 return z
             y = torch.empty_like(z, dtype=_BF if act else torch.float32)
             bio = (HP_BN_ACT | HP_BN_Z) if act else 0
@@ -897,6 +934,11 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.cfg = (desc, relu, train, res is not None)
         ctx.act = act
         ctx.links = (link_in, link_out, res_link)
+        ctx.bn_links = (bn_in, None)
+        if bn_out is not None and res is None and not act and train and link_out is None and res_link is None:
+            # producer of a BnLink: a plain fp32 unit in training mode whose output gradient arrives from ONE data gradient
+            bn_out.src = (z.detach(), mean, rstd, gamma.detach(), beta.detach(), relu)
+            ctx.bn_links = (bn_in, bn_out)
         return y
 
     @staticmethod
@@ -938,6 +980,16 @@ class _ConvBnAct(torch.autograd.Function):
                                                  rb.data_ptr(), gb.data_ptr(), 1 if trb else 0, dgb.data_ptr(), dbb.data_ptr(),
                                                  ws.data_ptr(), bio, st), "hp_bn_backward_dual")
                 res_link.done = (dzb, dgb, dbb)
+            elif (ctx.bn_links[1] is not None and ctx.bn_links[1].sums is not None and not has_res and in_mask is None
+                  and g is None and dy.dtype == torch.float32):
+                # the consumer's data gradient already took this unit's two sums (BnLink): coefficient kernel + apply pass only
+                sums, ctx.bn_links[1].sums = ctx.bn_links[1].sums, None
+                dz = torch.empty_like(z, dtype=hdt)
+                ws = torch.empty(nws // 4 + 2, dtype=torch.float32, device=x.device)
+                _lib.check(L.hp_bn_backward_presummed(dy.data_ptr(), z.data_ptr(), dz.data_ptr(), M, cout, mean.data_ptr(),
+                                                      rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu_flag else 0,
+                                                      1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), sums.data_ptr(),
+                                                      ws.data_ptr(), bio, st), "hp_bn_backward_presummed")
             else:
                 dz = torch.empty_like(z, dtype=hdt)
                 ws = torch.empty(nws // 4 + 2, dtype=torch.float32, device=x.device)
@@ -953,7 +1005,7 @@ class _ConvBnAct(torch.autograd.Function):
             stale = uses > 0 and e != ctx.use_epoch   # counted by another forward: nothing is known about this graph
             if uses > 1 or stale:
                 w._hp_shared = True        # every backward of this weight in this pass stays on the main stream
-            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask)
+            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask, bn_in=ctx.bn_links[0])
             if stale:
                 w._hp_shared = False
             elif uses > 0:
@@ -970,16 +1022,17 @@ class _ConvBnAct(torch.autograd.Function):
                     link_out.g, gres = g, None
             elif deferred:                         # shortcut unit: it receives dy itself and masks it on the fly
                 res_link.mask, gres = mask, dy
-        return dx, dw, dgamma, dbeta, gres, None, None, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, gres, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _ConvBiasToNCDHW(torch.autograd.Function):
     """Final 1^3 conv of the head: channels-last in, (B, C, D, H, W) out."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, bn_in=None):
         L = _lib.lib()
         x = x.contiguous()
+        ctx.bn_in = bn_in
         cout = w.shape[0]
         desc = _desc(x, cout, 1, 1, 0, False)
         st = _stream(x)
@@ -1010,9 +1063,9 @@ class _ConvBiasToNCDHW(torch.autograd.Function):
             dycl = torch.empty(b, d, h, wd_, c, dtype=torch.float32, device=x.device)
             _lib.check(L.hp_layout_transpose(dy.data_ptr(), dycl.data_ptr(), b, d * h * wd_, c, 0, st),
                        "hp_layout_transpose")
-            dx, dw = _conv_grads(desc, x, w, dycl, ctx.needs_input_grad[0])
+            dx, dw = _conv_grads(desc, x, w, dycl, ctx.needs_input_grad[0], bn_in=ctx.bn_in)
             dbias = dy.sum(dim=(0, 2, 3, 4))
-        return dx, dw, dbias
+        return dx, dw, dbias, None
 
 
 class _MaxPool3CL(torch.autograd.Function):
@@ -1039,14 +1092,14 @@ class _MaxPool3CL(torch.autograd.Function):
         return dx
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, res_link=None):
-    """x channels-last (B,D,H,W,C)."""
+def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, res_link=None, bn_in=None, bn_out=None):
+    """x channels-last (B,D,H,W,C).  bn_in / bn_out: BnLinks to the unit that produced x / to the one consumer of the output."""
     return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.kernel_size[0], conv.stride[0],
-                            conv.padding[0], False, relu, link_in, link_out, res_link)
+                            conv.padding[0], False, relu, link_in, link_out, res_link, bn_in, bn_out)
 
 
-def deconv_bn_relu(x, deconv, bn):
-    return _ConvBnAct.apply(x, deconv.weight, bn.weight, bn.bias, None, bn, 4, 2, 1, True, True)
+def deconv_bn_relu(x, deconv, bn, bn_in=None, bn_out=None):
+    return _ConvBnAct.apply(x, deconv.weight, bn.weight, bn.bias, None, bn, 4, 2, 1, True, True, None, None, None, bn_in, bn_out)
 
 
 class _StemConvBnReluPool(torch.autograd.Function):
@@ -1125,8 +1178,8 @@ def stem_conv_bn_relu_pool(x, conv, bn):
     return _StemConvBnReluPool.apply(x.reshape(b, d, h, w, 1), conv.weight, bn.weight, bn.bias, bn)
 
 
-def head_conv_to_ncdhw(x, conv):
-    return _ConvBiasToNCDHW.apply(x, conv.weight, conv.bias)
+def head_conv_to_ncdhw(x, conv, bn_in=None):
+    return _ConvBiasToNCDHW.apply(x, conv.weight, conv.bias, bn_in)
 
 
 # ---------------------------------------------------------------- decode + losses (rows L1-L3)

@@ -44,15 +44,17 @@ class Bottleneck(nn.Module):
             # The unit takes the block's raw output gradient plus the output sign mask (hip_ops.ResLink).
             rl = ops.ResLink() if torch.is_grad_enabled() else None
             res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link, res_link=rl)
-        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link)
-        o = ops.conv_bn_act(o, self.conv2, self.bn2, relu=True)
+        # bn1 and bn2 each feed ONE convolution: that convolution's data gradient takes their backward sums (hip_ops.BnLink)
+        b1, b2 = ops.bn_link(), ops.bn_link()
+        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link, bn_out=b1)
+        o = ops.conv_bn_act(o, self.conv2, self.bn2, relu=True, bn_in=b1, bn_out=b2)
         if self.downsample is not None:
             if link is not None:
                 link.arrivals = 2      # conv1 and the shortcut convolution both produce d(block input)
-            return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res, res_link=rl)
+            return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res, res_link=rl, bn_in=b2)
         if link is not None:
             link.arrivals = 1          # conv1 adds the identity-shortcut gradient parked by conv3's node
-        return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=x, link_out=link)
+        return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=x, link_out=link, bn_in=b2)
 
 
 class DeconvHead(nn.Module):
@@ -74,9 +76,12 @@ class DeconvHead(nn.Module):
 
     def forward(self, x):
         f = self.features
+        prev = None
         for i in range(0, len(f) - 1, 3):
-            x = ops.deconv_bn_relu(x, f[i], f[i + 1])
-        return ops.head_conv_to_ncdhw(x, f[-1])
+            nxt = ops.bn_link()
+            x = ops.deconv_bn_relu(x, f[i], f[i + 1], bn_in=prev, bn_out=nxt)
+            prev = nxt
+        return ops.head_conv_to_ncdhw(x, f[-1], prev)
 
 
 class ResNet(nn.Module):

@@ -592,3 +592,64 @@ def test_side_stream_weight_gradient_with_a_tensor_hook_or_shared_weight():
     g1, s1 = run(True)
     assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
     assert len(s0) == len(s1) and all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(s0, s1))
+
+
+@pytest.mark.parametrize("ca,cb,kb,transposed,dims", [
+    (64, 64, 3, False, (2, 4, 8, 8)),      # conv1 -> conv2 of a Bottleneck: 64-column tile, 3^3 consumer
+    (64, 256, 1, False, (2, 4, 8, 8)),     # conv2 -> conv3: 64-column tile, 1^3 consumer
+    (128, 128, 3, False, (1, 8, 8, 8)),    # 128-column tile
+    (256, 64, 1, False, (1, 4, 8, 8)),     # two N tiles of 128
+    (256, 256, 4, True, (1, 4, 4, 8)),     # deconvolution consumer (DeconvHead)
+    (256, 24, 1, False, (2, 4, 4, 8)),     # the head's 1^3 convolution behind the last deconvolution's BatchNorm (K = 24: flat loads)
+    (96, 64, 1, False, (1, 4, 8, 8)),      # 96 channels: not a whole number of 64-column tiles -> falls back, same result
+    (64, 64, 3, False, (1, 3, 5, 8)),      # 120 rows: not whole M tiles -> falls back
+])
+def test_bn_backward_sums_taken_by_the_consumers_data_gradient(ca, cb, kb, transposed, dims):
+    """hip_ops.BnLink (round 4): unit a = conv + BatchNorm + ReLU without residual, consumed by ONE convolution b.  b's data
+    gradient IS a's incoming gradient, so hp_conv3d_backward_data_bnsums takes a's two BatchNorm-backward sums from the tile in
+    hand (one read of z_a) and hp_bn_backward_presummed skips the reduction pass.  Every gradient of the chain equals the
+    un-linked evaluation (same arithmetic, different summation order: 1e-5) and the float64 reference; geometries the whole-tile
+    kernels do not cover fall back without a trace (sums stay None)."""
+    g = torch.Generator().manual_seed(100 + ca + cb + kb)
+    B, D, H, W = dims
+    conv_a, bn_a = torch.nn.Conv3d(32, ca, 1, bias=False), torch.nn.BatchNorm3d(ca)
+    conv_b = (torch.nn.ConvTranspose3d(ca, cb, 4, stride=2, padding=1, bias=False) if transposed
+              else torch.nn.Conv3d(ca, cb, kb, padding=kb // 2, bias=False))
+    bn_b = torch.nn.BatchNorm3d(cb)
+    with torch.no_grad():
+        for m in (conv_a, conv_b):
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.05)
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(1 + 0.2 * torch.randn(bn.weight.shape, generator=g))
+            bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, generator=g))
+    x = torch.randn(B, 32, D, H, W, generator=g)
+    import copy
+
+    ref = [copy.deepcopy(m).double().train() for m in (conv_a, bn_a, conv_b, bn_b)]
+    xr = x.double().requires_grad_(True)
+    o = F.relu(ref[3](ref[2](F.relu(ref[1](ref[0](xr))))))
+    gy = torch.randn(o.shape, generator=g)
+    (o * gy.double()).sum().backward()
+
+    mods = [m.cuda().train() for m in (conv_a, bn_a, conv_b, bn_b)]
+    results, taken = [], []
+    for linked in (True, False):
+        for m in mods:
+            m.zero_grad()
+        xg = cl(x).cuda().requires_grad_(True)
+        link = ops.BnLink() if linked else None
+        before = ops._bn_fused_calls[0]
+        ya = ops.conv_bn_act(xg, mods[0], mods[1], relu=True, bn_out=link)
+        yb = (ops.deconv_bn_relu(ya, mods[2], mods[3], bn_in=link) if transposed
+              else ops.conv_bn_act(ya, mods[2], mods[3], relu=True, bn_in=link))
+        (yb * cl(gy).cuda()).sum().backward()
+        results.append([ncdhw(xg.grad)] + [p.grad.clone() for m in mods for p in m.parameters()])
+        taken.append(ops._bn_fused_calls[0] - before)
+        if linked:
+            assert link.src is not None and link.sums is None      # handed over and consumed (or never produced)
+    whole = (B * D * H * W) % 128 == 0 and ca % 64 == 0 and (ca <= 64 or ca % 128 == 0)
+    assert taken == [1 if whole else 0, 0], (taken, whole)
+    refs = [xr.grad] + [p.grad for m in ref for p in m.parameters()]
+    for a, b, r in zip(results[0], results[1], refs):
+        assert rel_l2(a, b) < 1e-5          # linked vs un-linked: the same sums in another order
+        assert rel_l2(a, r) < 1e-4          # and the float64 reference

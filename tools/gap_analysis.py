@@ -13,7 +13,7 @@ steps = int(sys.argv[2])
 n = len(rows) // steps
 idx = int(sys.argv[3]) if len(sys.argv) > 3 else steps - 1
 # a step starts at the first launch of the forward (FeatureExtraction's replicate-padded convolution)
-marker = sys.argv[4] if len(sys.argv) > 4 else next((m for m in ("k_stencil_c1<1>", "k_dconv3_mfma<1>") if any(m in r[2] for r in rows)), "")
+marker = sys.argv[4] if len(sys.argv) > 4 else next((m for m in ("k_stencil_c1<1", "k_dconv3_mfma<1") if any(m in r[2] for r in rows)), "")
 starts = [i for i, r in enumerate(rows) if marker in r[2] and (i == 0 or marker not in rows[i - 1][2])]
 first = [i for j, i in enumerate(starts) if j == 0 or i - starts[j - 1] > n // 2]
 last = rows[first[idx]:first[idx + 1]] if idx + 1 < len(first) else rows[first[idx]:]
