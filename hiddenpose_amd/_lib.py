@@ -45,8 +45,8 @@ SIGNATURES = {
     "hp_conv3d_forward": (_i, [_vp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "hp_conv3d_backward_data": (_i, [_vp, _fp, _fp, _fp, _fp, _vp]),
     "hp_conv3d_backward_data_masked": (_i, [_vp, _fp, _fp, _fp, _fp, _vp, _vp]),
-    "hp_conv3d_backward_data_bnsums": (_i, [_vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _fp, _i, _vp, C.POINTER(C.c_int), _vp]),
-    "hp_bn_backward_presummed": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _vp, _i, _vp]),
+    "hp_conv3d_backward_data_bnsums": (_i, [_vp, _fp, _fp, _fp, _fp, _vp, _fp, _fp, _fp, _fp, _fp, _i, _vp, _vp, C.POINTER(C.c_int), _vp]),
+    "hp_bn_backward_presummed": (_i, [_fp, _fp, _fp, C.c_long, _i, _fp, _fp, _fp, _fp, _i, _i, _fp, _fp, _vp, _vp, _vp, _i, _vp]),
     "hp_conv3d_backward_weight": (_i, [_vp, _fp, _fp, _fp, _vp]),
     "hp_conv3d_backward_weight_split": (_i, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "hp_bn_train_finalize": (_i, [_vp, C.c_long, _i, C.c_float, C.c_float, _fp, _fp, _fp, _fp, _vp]),

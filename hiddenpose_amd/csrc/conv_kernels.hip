@@ -67,6 +67,7 @@ struct IgemmGeom {
   const float *bn_mean, *bn_rstd, *bn_gamma, *bn_beta;
   double* bn_sums;         // HP_STATS_SLOTS x 2 x Nout doubles: sum g, sum g * zhat with g = dy_a (.) [y_a > 0]
   int bn_relu;
+  const unsigned char* bn_mask;   // unit WITH residual: [y_a > 0] as hp_bn_apply's byte mask (one byte per channel quad) instead of z_a's sign
 };
 
 // m -> (b, z, y, x) on the per-class grid; shifts when the grid is a power of two (the usual case)
@@ -696,10 +697,12 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     // of the only consumer of y_a): its backward sums  s = sum g,  d = sum g * zhat  (g = dy_a (.) [y_a > 0], zhat = (z_a - mean)
     // * rstd; the expressions are k_bn_bwd_reduce's) are taken here, from the tile in hand and ONE read of the z_a tile, instead
     // of by a separate pass over dy_a and z_a.  Host-checked: every tile of a BNS launch is whole (the `fast` path).
-    [[maybe_unused]] __amdgpu_buffer_rsrc_t zrs = yrs;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t zrs = yrs, bmrs = mrs;
     [[maybe_unused]] float4 b_m = make_float4(0, 0, 0, 0), b_r = b_m, b_sc = b_m, b_sh = b_m, b_s = b_m, b_d = b_m;
     if constexpr (BNS) {
       zrs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bn_z + tile_el), 0, y_rec, 0x00020000);
+      if (g.bn_mask)
+        bmrs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bn_mask + (tile_el >> 2)), 0, hp_extent(y_el >> 2, tile_el >> 2, 1), 0x00020000);
       b_m = *(const float4*)(g.bn_mean + n0 + 4 * q_l);
       b_r = *(const float4*)(g.bn_rstd + n0 + 4 * q_l);
       if (g.bn_relu) {
@@ -725,12 +728,14 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
       float4 avb[K2];
       unsigned mkb[K2];
       [[maybe_unused]] float4 zvb[BNS ? K2 : 1];
+      [[maybe_unused]] unsigned bmb[BNS ? K2 : 1];
       if constexpr (BNS) {
 #pragma unroll
         for (int k2 = 0; k2 < K2; ++k2) {
           const int rowc = k2 * RPK;
           const unsigned so = (unsigned)(((rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31)) * g.Nout * 4);
           zvb[k2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(zrs, vo, so, 0));
+          bmb[k2] = g.bn_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(bmrs, vo >> 4, so >> 4, 0) : 0u;
         }
       }
       if (fast && addend) {
@@ -797,7 +802,13 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           if constexpr (BNS) {
             const float4 zz = zvb[k2];
             float4 gg = v;
-            if (g.bn_relu) {
+            if (g.bn_mask) {
+              const unsigned bm = bmb[k2];
+              gg.x = (bm & 1u) ? v.x : 0.f;
+              gg.y = (bm & 2u) ? v.y : 0.f;
+              gg.z = (bm & 4u) ? v.z : 0.f;
+              gg.w = (bm & 8u) ? v.w : 0.f;
+            } else if (g.bn_relu) {
               gg.x = fmaf(zz.x, b_sc.x, b_sh.x) > 0.f ? v.x : 0.f;
               gg.y = fmaf(zz.y, b_sc.y, b_sh.y) > 0.f ? v.y : 0.f;
               gg.z = fmaf(zz.z, b_sc.z, b_sh.z) > 0.f ? v.z : 0.f;
@@ -3031,9 +3042,9 @@ static bool launch_igemm_bns(const IgemmGeom& g, const void* X, const float* W, 
 
 extern "C" int hp_conv3d_backward_data_bnsums(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx, const void* addend,
                                               const unsigned char* addend_mask, const float* z, const float* mean,
-                                              const float* rstd, const float* gamma, const float* beta, int relu, double* sums,
-                                              int* fused, void* stream) {
-  HP_REQUIRE(d && dy && w_dgrad && dx && z && mean && rstd && sums && fused && (!relu || (gamma && beta)),
+                                              const float* rstd, const float* gamma, const float* beta, int relu,
+                                              const unsigned char* relu_mask, double* sums, int* fused, void* stream) {
+  HP_REQUIRE(d && dy && w_dgrad && dx && z && mean && rstd && sums && fused && (!relu || relu_mask || (gamma && beta)),
              "hp_conv3d_backward_data_bnsums: null argument");
   *fused = 0;
   ConvPlan p;
@@ -3050,6 +3061,7 @@ extern "C" int hp_conv3d_backward_data_bnsums(const hp_conv_desc* d, const void*
     g.bn_beta = beta;
     g.bn_sums = sums;
     g.bn_relu = relu ? 1 : 0;
+    g.bn_mask = relu ? relu_mask : nullptr;
     HP_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * g.Nout * HP_STATS_SLOTS, st));
     HP_PROF("conv_igemm_dgrad", st);
     if (launch_igemm_bns(g, dy, w_dgrad, dx, addend, addend_mask, st)) {

@@ -1170,11 +1170,12 @@ __global__ void k_bn_sum_slots(const double* __restrict__ slots, double* __restr
 
 extern "C" int hp_bn_backward_presummed(const void* dy, const void* z, void* dz, long M, int C, const float* mean,
                                         const float* rstd, const float* gamma, const float* beta_for_mask, int relu, int train,
-                                        float* dgamma, float* dbeta, const double* sums, void* workspace, int io, void* stream) {
+                                        float* dgamma, float* dbeta, const unsigned char* relu_mask, const double* sums,
+                                        void* workspace, int io, void* stream) {
   const int dy_half = (io & HP_BN_DY_BF16) ? 1 : 0, dz_half = (io & HP_BN_DZ_BF16) ? 1 : 0, z_half = (io & HP_BN_Z_BF16) ? 1 : 0;
   HP_REQUIRE(dy && z && dz && mean && rstd && gamma && sums && workspace && M > 0 && C > 0 && C % 4 == 0 && dy != dz,
              "hp_bn_backward_presummed: bad argument");
-  HP_REQUIRE(!relu || beta_for_mask, "hp_bn_backward_presummed: relu needs beta to rebuild the mask from z");
+  HP_REQUIRE(!relu || relu_mask || beta_for_mask, "hp_bn_backward_presummed: relu needs the byte mask, or beta to rebuild the mask from z");
   hipStream_t st = (hipStream_t)stream;
   double* red = (double*)workspace;
   float* ca = (float*)(red + 2 * C);
@@ -1188,9 +1189,13 @@ extern "C" int hp_bn_backward_presummed(const void* dy, const void* z, void* dz,
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
     const int iom = io_mode(C4, {dy_half, z_half, dz_half});
-    HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
-                  (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean, (const float4*)rstd,
-                  (const float4*)gamma, (const float4*)beta_for_mask, relu);
+    if (relu && relu_mask)
+      HP_LAUNCH_IOM(k_bn_bwd_apply_bytemask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+                    (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
+    else
+      HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+                    (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean, (const float4*)rstd,
+                    (const float4*)gamma, (const float4*)beta_for_mask, relu);
   }
   HP_CHECK_HIP(hipGetLastError());
   return HP_OK;

@@ -676,8 +676,32 @@ class BnLink:
     __slots__ = ("src", "sums")
 
     def __init__(self):
-        self.src = None    # (z, mean, rstd, gamma, beta, relu) of the producer, set by its forward
+        self.src = None    # (z, mean, rstd, gamma, beta, relu, byte mask or None) of the producer, set by its forward
         self.sums = None   # HP_STATS_SLOTS x 2C doubles, set by the consumer's backward
+
+
+# A Bottleneck's OUTPUT unit (bn3 + identity shortcut + ReLU) is consumed by the next block: by its conv1 and by its identity
+# shortcut.  The block-output gradient is complete in the epilogue of that conv1's data gradient (it adds the parked shortcut
+# gradient), so conv1 of the NEXT block is the consumer of this unit's BnLink.  The two forwards do not see each other (blocks
+# sit in an nn.Sequential): the producer offers its link together with a weak reference to its output tensor, and the next
+# block takes it if -- and only if -- its input IS that tensor.
+_res_bn_pending = [None]
+
+
+# OFF by default (HP_BN_FUSE_RES=1 turns it on): measured at the headline shape, same box -- the reduction passes it removes
+# are worth -8.1 ms/step, but its consumers are the 1^3 data gradients with 4 x planes output channels, which are HBM-bound on
+# exactly that output, and the extra read of z_a (as large as the output) costs them +8.3 ms: 472.3 ms with it, 468.4 without
+# (bn1 / bn2 hand-overs alone; 474.0 with neither).
+_BN_FUSE_RES = __import__("os").environ.get("HP_BN_FUSE_RES", "0") != "0"
+
+
+def offer_res_bn(y, link) -> None:
+    _res_bn_pending[0] = None if (link is None or not _BN_FUSE_RES) else (__import__("weakref").ref(y), link)
+
+
+def take_res_bn(x):
+    p, _res_bn_pending[0] = _res_bn_pending[0], None
+    return p[1] if (p is not None and p[0]() is x) else None
 
 
 _BN_FUSE = __import__("os").environ.get("HP_BN_FUSE", "1") != "0"
@@ -786,13 +810,13 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=No
         inplace = addend is not None and addend_mask is None and desc.k == 1 and desc.stride == 2 and not desc.transposed
         dx = addend if inplace else torch.empty_like(x)
         if bn_in is not None and bn_in.src is not None and not inplace and desc.io == 0 and desc.precision == 0 and x.dtype == torch.float32:
-            zs, ms, rs, gs, bs, relu_s = bn_in.src
+            zs, ms, rs, gs, bs, relu_s, mask_s = bn_in.src
             sums = torch.empty(_lib.STATS_SLOTS * 2 * x.shape[-1], dtype=torch.float64, device=x.device)
             fused = _C.c_int(0)
             _lib.check(L.hp_conv3d_backward_data_bnsums(_C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _lib.ptr(addend),
                                                         _lib.ptr(addend_mask), zs.data_ptr(), ms.data_ptr(), rs.data_ptr(),
-                                                        gs.data_ptr(), bs.data_ptr(), 1 if relu_s else 0, sums.data_ptr(),
-                                                        _C.byref(fused), st), "hp_conv3d_backward_data_bnsums")
+                                                        gs.data_ptr(), bs.data_ptr(), 1 if relu_s else 0, _lib.ptr(mask_s),
+                                                        sums.data_ptr(), _C.byref(fused), st), "hp_conv3d_backward_data_bnsums")
             if fused.value:
                 bn_in.sums = sums
                 _bn_fused_calls[0] += 1
@@ -935,10 +959,15 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.act = act
         ctx.links = (link_in, link_out, res_link)
         ctx.bn_links = (bn_in, None)
-        if bn_out is not None and res is None and not act and train and link_out is None and res_link is None:
-            # producer of a BnLink: a plain fp32 unit in training mode whose output gradient arrives from ONE data gradient
-            bn_out.src = (z.detach(), mean, rstd, gamma.detach(), beta.detach(), relu)
-            ctx.bn_links = (bn_in, bn_out)
+        if bn_out is not None and not act and train and res_link is None:
+            if res is None and link_out is None:
+                # producer of a BnLink: a plain fp32 unit in training mode whose output gradient arrives from ONE data gradient
+                bn_out.src = (z.detach(), mean, rstd, gamma.detach(), beta.detach(), relu, None)
+                ctx.bn_links = (bn_in, bn_out)
+            elif res is not None and relu and mask is not None and raff is None:
+                # a block's output unit with an identity shortcut: the mask is the byte mask of the output (see offer_res_bn)
+                bn_out.src = (z.detach(), mean, rstd, gamma.detach(), beta.detach(), True, mask)
+                ctx.bn_links = (bn_in, bn_out)
         return y
 
     @staticmethod
@@ -980,16 +1009,17 @@ class _ConvBnAct(torch.autograd.Function):
                                                  rb.data_ptr(), gb.data_ptr(), 1 if trb else 0, dgb.data_ptr(), dbb.data_ptr(),
                                                  ws.data_ptr(), bio, st), "hp_bn_backward_dual")
                 res_link.done = (dzb, dgb, dbb)
-            elif (ctx.bn_links[1] is not None and ctx.bn_links[1].sums is not None and not has_res and in_mask is None
-                  and g is None and dy.dtype == torch.float32):
+            elif (ctx.bn_links[1] is not None and ctx.bn_links[1].sums is not None and g is None and dy.dtype == torch.float32
+                  and ((not has_res and in_mask is None) or (has_res and deferred and in_mask is mask))):
                 # the consumer's data gradient already took this unit's two sums (BnLink): coefficient kernel + apply pass only
+                # (a block's output unit: the apply pass gates dy with the same byte mask the sums were taken with)
                 sums, ctx.bn_links[1].sums = ctx.bn_links[1].sums, None
                 dz = torch.empty_like(z, dtype=hdt)
                 ws = torch.empty(nws // 4 + 2, dtype=torch.float32, device=x.device)
                 _lib.check(L.hp_bn_backward_presummed(dy.data_ptr(), z.data_ptr(), dz.data_ptr(), M, cout, mean.data_ptr(),
                                                       rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if relu_flag else 0,
-                                                      1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), sums.data_ptr(),
-                                                      ws.data_ptr(), bio, st), "hp_bn_backward_presummed")
+                                                      1 if train else 0, dgamma.data_ptr(), dbeta.data_ptr(), _lib.ptr(in_mask),
+                                                      sums.data_ptr(), ws.data_ptr(), bio, st), "hp_bn_backward_presummed")
             else:
                 dz = torch.empty_like(z, dtype=hdt)
                 ws = torch.empty(nws // 4 + 2, dtype=torch.float32, device=x.device)
@@ -1005,7 +1035,8 @@ class _ConvBnAct(torch.autograd.Function):
             stale = uses > 0 and e != ctx.use_epoch   # counted by another forward: nothing is known about this graph
             if uses > 1 or stale:
                 w._hp_shared = True        # every backward of this weight in this pass stays on the main stream
-            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask, bn_in=ctx.bn_links[0])
+            # (a block input reaches two convolutions: its gradient is complete only in the one that runs last)
+            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask, bn_in=ctx.bn_links[0] if last else None)
             if stale:
                 w._hp_shared = False
             elif uses > 0:

@@ -36,6 +36,11 @@ class Bottleneck(nn.Module):
         # The block input feeds two consumers; their gradients are summed inside the data-gradient GEMM that
         # finishes last (hip_ops.GradLink) instead of by a separate accumulation pass.
         link = ops.GradLink() if (torch.is_grad_enabled() and x.requires_grad) else None
+        # the BatchNorm-backward sums of the PREVIOUS block's output unit are taken by this block's conv1 data gradient when that is
+        # where the block-input gradient becomes complete: identity blocks with a gradient link (hip_ops.offer_res_bn)
+        prev_out = ops.take_res_bn(x)
+        if self.downsample is not None or link is None:
+            prev_out = None
         res = rl = None
         if self.downsample is not None:
             # The shortcut unit is recorded FIRST so that its backward runs LAST: conv1's dense data gradient then
@@ -46,7 +51,7 @@ class Bottleneck(nn.Module):
             res = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_in=link, res_link=rl)
         # bn1 and bn2 each feed ONE convolution: that convolution's data gradient takes their backward sums (hip_ops.BnLink)
         b1, b2 = ops.bn_link(), ops.bn_link()
-        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link, bn_out=b1)
+        o = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link, bn_in=prev_out, bn_out=b1)
         o = ops.conv_bn_act(o, self.conv2, self.bn2, relu=True, bn_in=b1, bn_out=b2)
         if self.downsample is not None:
             if link is not None:
@@ -54,7 +59,10 @@ class Bottleneck(nn.Module):
             return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=res, res_link=rl, bn_in=b2)
         if link is not None:
             link.arrivals = 1          # conv1 adds the identity-shortcut gradient parked by conv3's node
-        return ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=x, link_out=link, bn_in=b2)
+        b3 = ops.bn_link() if (link is not None and ops._BN_FUSE_RES) else None
+        y = ops.conv_bn_act(o, self.conv3, self.bn3, relu=True, residual=x, link_out=link, bn_in=b2, bn_out=b3)
+        ops.offer_res_bn(y, b3)
+        return y
 
 
 class DeconvHead(nn.Module):
@@ -76,7 +84,7 @@ class DeconvHead(nn.Module):
 
     def forward(self, x):
         f = self.features
-        prev = None
+        prev = ops.take_res_bn(x)      # layer4's last block: its output feeds the first deconvolution only
         for i in range(0, len(f) - 1, 3):
             nxt = ops.bn_link()
             x = ops.deconv_bn_relu(x, f[i], f[i + 1], bn_in=prev, bn_out=nxt)

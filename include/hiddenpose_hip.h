@@ -176,13 +176,15 @@ int hp_conv3d_backward_data_masked(const hp_conv_desc* d, const void* dy, const 
  * convolution (y_a = [relu](BN(z_a)) is this convolution's input and has no other consumer, so dx IS dy_a): while a tile of
  * dx is in hand the kernel reads the same tile of z_a once and accumulates  sum g  and  sum g * (z_a - mean) * rstd  per
  * channel, g = dx (.) [gamma * zhat + beta > 0] (relu != 0) or dx (Bottleneck.forward / DeconvHead.forward,
- * posenet3d_50.py:75-95,129-153).  sums: HP_STATS_SLOTS x 2 x Cin doubles (partial vectors, zeroed by the call), to be
+ * posenet3d_50.py:75-95,129-153); for a unit WITH a residual (the block's output unit, whose output also feeds the next block's
+ * identity shortcut: dx is then the complete block-output gradient, addend included) relu_mask = the byte mask hp_bn_apply wrote.  sums: HP_STATS_SLOTS x 2 x Cin doubles (partial vectors, zeroed by the call), to be
  * handed to hp_bn_backward_presummed, whose separate pass over dy_a and z_a it replaces.  Exact-fp32 tensors, a dense
  * stride-1 (or ConvTranspose3d) data gradient with B*D*H*W % 128 == 0 and Cin % 64 == 0 (% 128 beyond 64) only: *fused is
  * set to 1 when the sums were taken, to 0 when the call fell back to the plain data gradient (sums untouched). */
 int hp_conv3d_backward_data_bnsums(const hp_conv_desc* d, const void* dy, const float* w_dgrad, void* dx, const void* addend,
                                    const unsigned char* addend_mask, const float* z, const float* mean, const float* rstd,
-                                   const float* gamma, const float* beta, int relu, double* sums, int* fused, void* stream);
+                                   const float* gamma, const float* beta, int relu, const unsigned char* relu_mask, double* sums,
+                                   int* fused, void* stream);
 /* dw_packed (same layout as w_fwd) is zeroed and accumulated by the call. */
 int hp_conv3d_backward_weight(const hp_conv_desc* d, const void* x, const void* dy, float* dw_packed, void* stream);
 /* How hp_conv3d_backward_weight splits its reduction over M = B * output voxels for this descriptor: `msplit` chunks of
@@ -231,10 +233,10 @@ int hp_bn_backward(const void* dy, const float* y, const void* z, void* g_out, v
                    void* stream);
 /* hp_bn_backward of a unit WITHOUT residual whose two sums were already taken by the data gradient that produced dy
  * (hp_conv3d_backward_data_bnsums): only the coefficient kernel and the apply pass dz = a g + b z + c run; the ReLU mask is
- * rebuilt from z and beta_for_mask as in hp_bn_backward.  workspace: hp_bn_backward_workspace_bytes(C). */
+ * relu_mask (a residual unit's byte mask) if given, else rebuilt from z and beta_for_mask as in hp_bn_backward.  workspace: hp_bn_backward_workspace_bytes(C). */
 int hp_bn_backward_presummed(const void* dy, const void* z, void* dz, long M, int C, const float* mean, const float* rstd,
                              const float* gamma, const float* beta_for_mask, int relu, int train, float* dgamma, float* dbeta,
-                             const double* sums, void* workspace, int io, void* stream);
+                             const unsigned char* relu_mask, const double* sums, void* workspace, int io, void* stream);
 /* Two BatchNorm units fed by the same gradient g = dy (.) relu_mask -- bn3 of the main branch (a) and the BatchNorm
  * of the shortcut convolution (b) of a Bottleneck with `downsample` (posenet3d_50.py:86-93): one reduction and one
  * apply pass serve both (dy and the mask are read once per pass instead of twice).  Same arithmetic per unit as

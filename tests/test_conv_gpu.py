@@ -653,3 +653,63 @@ def test_bn_backward_sums_taken_by_the_consumers_data_gradient(ca, cb, kb, trans
     for a, b, r in zip(results[0], results[1], refs):
         assert rel_l2(a, b) < 1e-5          # linked vs un-linked: the same sums in another order
         assert rel_l2(a, r) < 1e-4          # and the float64 reference
+
+
+def test_block_output_units_hand_their_sums_to_the_next_blocks_conv1():
+    """Three Bottlenecks in an nn.Sequential (a shortcut-convolution block, then two identity blocks; 64 planes, 256 channels,
+    1024 voxels) followed by a deconvolution unit, float64 reference built from the same modules.  Besides bn1 / bn2 of every
+    block (test above), the OUTPUT units of blocks 1 and 2 (bn3 + identity shortcut) hand their BatchNorm-backward sums to the
+    data gradient in which the block-output gradient becomes complete -- conv1 of the next block (masked shortcut addend
+    included), the deconvolution for the last one -- through hip_ops.offer_res_bn / take_res_bn; block 0's output unit
+    (paired with the shortcut's BatchNorm in the dual pass) does not.  With the hand-overs off the same gradients come out.
+    (The block-output hand-over is built and tested but OFF by default, HP_BN_FUSE_RES: its consumers are the HBM-bound 1^3
+    data gradients with 4 x planes output channels, and the extra read of z costs them what the saved pass gains.)"""
+    import copy
+
+    from hiddenpose_amd.posenet3d_50 import Bottleneck
+
+    g = torch.Generator().manual_seed(77)
+    planes, cin = 64, 128
+    ds = torch.nn.Sequential(torch.nn.Conv3d(cin, planes * 4, 1, bias=False), torch.nn.BatchNorm3d(planes * 4))
+    net = torch.nn.Sequential(Bottleneck(cin, planes, 1, ds), Bottleneck(planes * 4, planes), Bottleneck(planes * 4, planes))
+    dec, dbn = torch.nn.ConvTranspose3d(planes * 4, 128, 4, stride=2, padding=1, bias=False), torch.nn.BatchNorm3d(128)
+    with torch.no_grad():
+        for prm in list(net.parameters()) + list(dec.parameters()) + list(dbn.parameters()):
+            prm.copy_(torch.randn(prm.shape, generator=g) * (0.08 if prm.dim() > 1 else 0.3) + (1.0 if prm.dim() == 1 else 0.0))
+    B, D = 2, 8
+    x = torch.randn(B, cin, D, D, D, generator=g)
+    refn, refd, refb = copy.deepcopy(net).double().train(), copy.deepcopy(dec).double(), copy.deepcopy(dbn).double().train()
+    xr = x.double().requires_grad_(True)
+    t = torch.relu(xr * 1.0)
+    for m in refn:
+        o = torch.relu(m.bn1(m.conv1(t)))
+        o = torch.relu(m.bn2(m.conv2(o)))
+        o = m.bn3(m.conv3(o))
+        t = torch.relu(o + (m.downsample(t) if m.downsample is not None else t))
+    yr = torch.relu(refb(refd(t)))
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy.double()).sum().backward()
+    ref_grads = [xr.grad] + [p.grad for p in list(refn.parameters()) + list(refd.parameters()) + list(refb.parameters())]
+
+    net, dec, dbn = net.cuda().train(), dec.cuda(), dbn.cuda().train()
+    out = []
+    for fuse in (True, False):
+        prev = (ops._BN_FUSE, ops._BN_FUSE_RES)
+        ops._BN_FUSE, ops._BN_FUSE_RES = fuse, fuse      # the block-output hand-over is opt-in (see hip_ops._BN_FUSE_RES)
+        try:
+            for p in list(net.parameters()) + list(dec.parameters()) + list(dbn.parameters()):
+                p.grad = None
+            before = ops._bn_fused_calls[0]
+            xg = cl(x).cuda().requires_grad_(True)
+            h = net(torch.relu(xg * 1.0))
+            y = ops.deconv_bn_relu(h, dec, dbn, bn_in=ops.take_res_bn(h))
+            (y * cl(gy).cuda()).sum().backward()
+            out.append(([ncdhw(xg.grad)] + [p.grad.clone() for p in list(net.parameters()) + list(dec.parameters()) + list(dbn.parameters())],
+                        ops._bn_fused_calls[0] - before))
+        finally:
+            ops._BN_FUSE, ops._BN_FUSE_RES = prev
+    # 3 blocks x (bn1, bn2) + the output units of blocks 1 and 2 (block 0's is the dual pass with its shortcut BatchNorm)
+    assert out[0][1] == 8 and out[1][1] == 0, (out[0][1], out[1][1])
+    for a, b, r in zip(out[0][0], out[1][0], ref_grads):
+        assert rel_l2(a, b) < 2e-5          # with and without the hand-over: the same sums in another order
+        assert rel_l2(a, r) < 2e-2          # float64: ten train-mode BatchNorms over 1024 values and their ReLU masks deep (1e-3 .. 5e-3)
