@@ -609,7 +609,8 @@ def main():
         B = args.batch
     cfg = make_cfg(T, N, device=local, conv_precision=args.conv_precision)
     from hiddenpose_amd import hip_ops as _ops
-    _ops.set_wgrad_async(not args.no_wgrad_stream)
+    wgrad_stream = _ops._WGRAD_ASYNC and not args.no_wgrad_stream     # HP_WGRAD_STREAM=0 in the environment switches it off as well
+    _ops.set_wgrad_async(wgrad_stream)
     bf16 = args.conv_precision != "fp32"
     # split modes issue 3 / 6 bf16 MFMAs per algorithmic product: the useful-FLOP ceiling shrinks accordingly
     mfma_terms = {"fp32": 1, "bf16": 1, "bf16s": 1, "bf16x3": 3, "bf16x6": 6}[args.conv_precision]
@@ -699,7 +700,7 @@ def main():
     profiled_ms = 1e3 * (time.perf_counter() - tp0) / psteps
     _lib.profile_enable(False)
     prof = _lib.profile_read()
-    _ops.set_wgrad_async(not args.no_wgrad_stream)
+    _ops.set_wgrad_async(wgrad_stream)
     dp_ab = None
     if reducer is not None and not args.no_extra:
         # the same step with each exchange algorithm, 3 timed steps each (1 warm-up), slowest rank: the first multi-GPU run
@@ -760,7 +761,7 @@ def main():
             "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
                                    f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
                                    "accumulation) with fp32 LCT, U-Net, norms, losses and " + ("bf16 regressor activations / activation gradients in HBM (fp32 raw conv outputs, statistics, weights)" if args.conv_precision == "bf16s" else "fp32 tensors in HBM") if bf16 else "fp32") + ", random-init weights"
-                                   + (", weight gradients on a second stream" if not args.no_wgrad_stream else ", weight gradients on the main stream"),
+                                   + (", weight gradients on a second stream" if wgrad_stream else ", weight gradients on the main stream"),
                        "global_batch": B * world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": args.dp_algo if reducer_on else None, "ranks": ranks_seen,
@@ -821,7 +822,7 @@ def main():
             if roof is not None:
                 roof["note"] = (f"per-kernel times: HIP events over {psteps} appended step(s) of the same run with every kernel on ONE stream "
                                 f"(un-overlapped, {profiled_ms:.1f} ms/step incl. ~4 ms of event overhead); the timed region runs the weight "
-                                "gradients on a second stream" if not args.no_wgrad_stream else
+                                "gradients on a second stream" if wgrad_stream else
                                 f"per-kernel times: HIP events over {psteps} appended step(s) of the same run")
             line["unoverlapped_profiled_ms_per_step"] = round(profiled_ms, 3)
             cf = posenet_conv_flops(T, N, B)

@@ -745,10 +745,10 @@ def _wgrad_side_stream(device):
         return None
     s = _side_streams.get(device)
     if s is None:
-        # LOW priority (HP_WGRAD_PRIO, default 1 = below the default stream's 0; torch clamps to what HIP offers): the main
-        # stream carries backward's critical path (BatchNorm backward -> data gradient -> next unit) and should win every
-        # workgroup slot it can use; the weight gradients fill what is left
-        s = _side_streams[device] = torch.cuda.Stream(device, priority=int(__import__("os").environ.get("HP_WGRAD_PRIO", "1")))
+        # Same priority as the training stream.  HIP offers two levels on this device (priority_range() = (0, -1)); giving the
+        # training stream -- backward's critical path -- the high one, or the weight gradients the high one, measured 455.5 /
+        # 455.2 ms against 456.6 (HP_MAIN_PRIO in bench.py, HP_WGRAD_PRIO here: A/B hooks): inside the noise
+        s = _side_streams[device] = torch.cuda.Stream(device, priority=int(__import__("os").environ.get("HP_WGRAD_PRIO", "0")))
     task = torch._C._current_graph_task_id()
     if _joined_task[0] != task:
         _joined_task[0] = task
@@ -770,10 +770,9 @@ _HOLD_DEPTH = int(__import__("os").environ.get("HP_WGRAD_HOLD", "4"))
 
 
 def _hold(device, side, main, tensors):
-    from collections import deque
     q = _held.get(device)
     if q is None:
-        q = _held[device] = deque()
+        q = _held[device] = __import__("collections").deque()
     ev = torch.cuda.Event()
     ev.record(side)
     q.append((ev, tensors))
