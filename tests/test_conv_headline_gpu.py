@@ -298,3 +298,148 @@ def test_headline_geometry_convolution_vs_float64(layer, capsys):
     with capsys.disabled():
         print(f"\n[{name:12s} {cin:4d}->{cout:4d} k{k} s{s}{' T' if tr else ''} in{din}] " +
               "  ".join(f"{w_} rel {a:.1e} max {b:.1e}" for w_, a, b in report), end="")
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_headline_geometry_convolution_bf16_storage_vs_float64(layer, capsys):
+    """The same 33 shapes at the same geometry in BASELINE configs[2]'s per-GPU arithmetic (`bf16s`: bf16 tensors in HBM, bf16
+    matrix cores, fp32 accumulation; the stem's tensors stay fp32): forward with the statistics epilogue, data gradient and weight
+    gradient (dense block and sparse rows) through the C ABI exactly as hip_ops calls them, against float64 evaluations on the
+    bf16-ROUNDED operands.  Products of bf16 values are exact in fp32, so fp32 results (weight gradients, the stem, the head's
+    output) keep the fp32 bars; bf16 outputs add their own rounding (2^-9 per element: measured rel-L2 1.7e-3 on every layer;
+    largest error over rms 1e-2 .. 3.5e-2 -- the strided shortcut gradients are 7/8 zeros, so their largest elements are many rms:
+    bars 5e-3 / 6e-2).  This is what puts the bf16 tile loaders (`k_igemm<..., XH, GL>`), the 2-byte row offsets of `k_wgrad_blh` and its
+    host-side span tests under the 2.1 GB tensors of layer 1."""
+    name, cin, cout, k, s, p, tr, din = layer
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    seed = 3000 + [l[0] for l in LAYERS].index(name)
+    torch.manual_seed(seed)
+    prev = ops.set_conv_precision("bf16s")
+    try:
+        half = cin > 1                                     # the stem reads its single-channel input as fp32
+        head = name == "head"
+        dt = torch.bfloat16 if half else torch.float32
+        x = torch.randn(B, *din, cin, device=dev).to(dt)
+        w = (torch.randn((cin, cout, k, k, k) if tr else (cout, cin, k, k, k), device=dev) * 0.05)
+        desc = ops._desc(x, cout, k, s, p, tr)
+        dout = ops._out_dims(desc)
+        Mi, Mo = B * din[0] * din[1] * din[2], B * dout[0] * dout[1] * dout[2]
+        st = ops._stream(x)
+        whf, whd = ops._w_half(desc, half, cin), ops._w_half(desc, half, cout)
+        wf, _ = ops._pack(desc, w, True, False, half=whf)
+        _, wd = ops._pack(desc, w, False, True, half=whd)
+        wr = w.bfloat16().double().cpu().numpy().reshape(w.shape[0], w.shape[1], k ** 3)     # what the matrix cores multiply
+        if tr:
+            w_fwd = np.ascontiguousarray(wr.transpose(2, 0, 1)).reshape(k ** 3 * cin, cout)
+            w_dgr = np.ascontiguousarray(wr.transpose(2, 1, 0)).reshape(k ** 3 * cout, cin)
+        else:
+            w_fwd = np.ascontiguousarray(wr.transpose(2, 1, 0)).reshape(k ** 3 * cin, cout)
+            w_dgr = np.ascontiguousarray(wr.transpose(2, 0, 1)).reshape(k ** 3 * cout, cin)
+        xr = x.bfloat16()                                   # (identity for the bf16 tensors; the stem's fp32 input as rounded on load)
+        eb = 2 if half else 4
+        report = []
+
+        # ---------------------------------------------------------------- forward
+        y_half = half and not head                          # the head's output stays fp32 (hip_ops._ConvBiasToNCDHW)
+        y = torch.empty(B, *dout, cout, device=dev, dtype=torch.bfloat16 if y_half else torch.float32)
+        bias = torch.randn(cout, device=dev) if head else None
+        stats = None if head else torch.empty(_lib.STATS_SLOTS * 2 * cout, dtype=torch.float64, device=dev)
+        desc.io = (ops.HP_IO_X if half else 0) | (ops.HP_IO_Y if y_half else 0) | (ops.HP_IO_W if whf else 0)
+        _lib.check(L.hp_conv3d_forward(C.byref(desc), x.data_ptr(), wf.data_ptr(), _lib.ptr(bias), y.data_ptr(), _lib.ptr(stats), st),
+                   "hp_conv3d_forward")
+        special = _marks(cout * (2 if y_half else 4), Mo) + _to_rowspace(_marks(cin * eb, Mi), din, dout)
+        rows = _sample_rows(Mo, special, seed).to(dev)
+        want = _gather(xr, din, rows, dout, k, 2 if tr else s, p, divisible=tr).double().cpu().numpy().reshape(rows.numel(), -1) @ w_fwd
+        if head:
+            want = want + bias.double().cpu().numpy()[None, :]
+        got = y.reshape(Mo, cout)[rows].float().cpu().numpy()
+        report.append(("fwd",) + (_check(got, want, f"{name} forward", 5e-3, 6e-2) if y_half else _check(got, want, f"{name} forward", 1e-5, 1e-4)))
+        if stats is not None:                               # from the fp32 accumulators, i.e. before y was rounded
+            s2 = sum((y.reshape(B, -1, cout)[b].double() ** 2).sum(0) for b in range(B)).cpu().numpy()
+            np.testing.assert_allclose(stats.view(_lib.STATS_SLOTS, 2 * cout).sum(0).cpu().numpy()[cout:], s2, rtol=3e-3 if y_half else 1e-6)
+        del y
+
+        # ---------------------------------------------------------------- data gradient
+        gy = torch.randn(B, *dout, cout, device=dev).to(dt)
+        dx = torch.empty_like(x)
+        desc.io = (ops.HP_IO_X | ops.HP_IO_DX | ops.HP_IO_DY if half else 0) | (ops.HP_IO_W if whd else 0)
+        _lib.check(L.hp_conv3d_backward_data(C.byref(desc), gy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, st), "hp_conv3d_backward_data")
+        gr = gy.bfloat16()
+        special = _marks(cin * eb, Mi) + _to_rowspace(_marks(cout * eb, Mo), dout, din)
+        rows_i = _sample_rows(Mi, special, seed + 1).to(dev)
+        want = _gather(gr, dout, rows_i, din, k, 2 if tr else s, p, divisible=not tr).double().cpu().numpy().reshape(rows_i.numel(), -1) @ w_dgr
+        got = dx.reshape(Mi, cin)[rows_i].float().cpu().numpy()
+        report.append(("dgrad",) + (_check(got, want, f"{name} data gradient", 5e-3, 6e-2) if half else _check(got, want, f"{name} data gradient", 1e-5, 1e-4)))
+        del dx
+
+        # ---------------------------------------------------------------- weight gradient (fp32 out: exact products of bf16 operands)
+        desc.io = ops.HP_IO_X | ops.HP_IO_DX | ops.HP_IO_DY if half else 0
+        dwp = torch.empty(int(L.hp_conv3d_packed_weight_elems(C.byref(desc))), device=dev)
+
+        def wgrad(xx, gg):
+            _lib.check(L.hp_conv3d_backward_weight(C.byref(desc), xx.data_ptr(), gg.data_ptr(), dwp.data_ptr(), st), "hp_conv3d_backward_weight")
+            if ops._same_as_packed(desc):
+                return dwp.view_as(w).clone()
+            dw = torch.empty_like(w)
+            _lib.check(L.hp_conv3d_unpack_wgrad(C.byref(desc), dwp.data_ptr(), dw.data_ptr(), st), "hp_conv3d_unpack_wgrad")
+            return dw
+
+        dw = wgrad(x, gy)
+        g = torch.Generator().manual_seed(seed + 2)
+        co_s = torch.randperm(cout, generator=g)[:16].sort().values.to(dev)
+        ci_s = torch.randperm(cin, generator=g)[:16].sort().values.to(dev)
+        tap_s = torch.randperm(k ** 3, generator=g)[:4].sort().values.tolist()
+        dense_got, dense_want = [], []
+        gyc = gr.reshape(B, *dout, cout)[..., co_s].double()
+        xc = xr.reshape(B, *din, cin)[..., ci_s].double()
+        for t in tap_s:
+            kd, kh, kw = t // (k * k), (t // k) % k, t % k
+            if tr:
+                pad = torch.nn.functional.pad(gyc, (0, 0, p, p, p, p, p, p))
+                sh = pad[:, kd:kd + 2 * din[0]:2, kh:kh + 2 * din[1]:2, kw:kw + 2 * din[2]:2, :]
+                dense_want.append(xc.reshape(Mi, -1).T @ sh.reshape(Mi, -1))
+                dense_got.append(dw[ci_s][:, co_s][:, :, kd, kh, kw].double())
+            else:
+                pad = torch.nn.functional.pad(xc, (0, 0, p, p, p, p, p, p))
+                sh = pad[:, kd:kd + s * dout[0]:s, kh:kh + s * dout[1]:s, kw:kw + s * dout[2]:s, :]
+                dense_want.append(gyc.reshape(Mo, -1).T @ sh.reshape(Mo, -1))
+                dense_got.append(dw[co_s][:, ci_s][:, :, kd, kh, kw].double())
+            del pad, sh
+        report.append(("wgrad",) + _check(torch.stack(dense_got).cpu().numpy(), torch.stack(dense_want).cpu().numpy(),
+                                          f"{name} weight gradient (dense)", 2e-5, 1e-4))
+        del gyc, xc, dw
+        msplit, chunk = C.c_long(0), C.c_long(0)
+        _lib.check(L.hp_conv3d_backward_weight_split(C.byref(desc), C.byref(msplit), C.byref(chunk)), "hp_conv3d_backward_weight_split")
+        msplit, chunk = msplit.value, chunk.value
+        Mr = Mi if tr else Mo
+        seams = []
+        for c in sorted({1, 2, msplit // 2, msplit - 1, msplit}):
+            if 0 < c and c * chunk - 1 < Mr:
+                seams += [c * chunk - 1, c * chunk]
+        live = sorted({r for r in ([0, Mr - 1, Mr - 2, Mr - 33] + seams + _marks((cin if tr else cout) * eb, Mr)
+                                   + torch.randint(0, Mr, (8,), generator=g).tolist()) if 0 <= r < Mr})[:48]
+        live_t = torch.tensor(live, dtype=torch.int64, device=dev)
+        if tr:
+            xs = torch.zeros_like(x)
+            xs.reshape(Mi, cin)[live_t] = x.reshape(Mi, cin)[live_t]
+            dw = wgrad(xs, gy)
+            rows_v = xs.reshape(Mi, cin)[live_t].bfloat16().double().cpu().numpy()
+            pt = _gather(gr, dout, live_t, din, k, 2, p, divisible=False).double().cpu().numpy()
+            want = (rows_v.T @ pt.reshape(len(live), -1)).reshape(cin, k ** 3, cout).transpose(0, 2, 1)
+            del xs
+        else:
+            gs = torch.zeros_like(gy)
+            gs.reshape(Mo, cout)[live_t] = gy.reshape(Mo, cout)[live_t]
+            dw = wgrad(x, gs)
+            rows_v = gs.reshape(Mo, cout)[live_t].bfloat16().double().cpu().numpy()     # (the stem's fp32 dz is rounded on load)
+            pt = _gather(xr, din, live_t, dout, k, s, p, divisible=False).double().cpu().numpy()
+            want = (rows_v.T @ pt.reshape(len(live), -1)).reshape(cout, k ** 3, cin).transpose(0, 2, 1)
+            del gs
+        report.append((f"wgrad-sparse[{len(live)} rows]",) + _check(dw.cpu().numpy().reshape(want.shape), want,
+                                                                     f"{name} weight gradient (sparse rows)", 1e-6, 1e-5))
+    finally:
+        ops.set_conv_precision(prev)
+    with capsys.disabled():
+        print(f"\n[bf16s {name:12s} {cin:4d}->{cout:4d} k{k} s{s}{' T' if tr else ''}] " +
+              "  ".join(f"{w_} rel {a:.1e} max {b:.1e}" for w_, a, b in report), end="")
