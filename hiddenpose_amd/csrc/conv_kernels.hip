@@ -204,7 +204,7 @@ __device__ __attribute__((aligned(256))) unsigned int g_zero_row[64];
 // returns 0.  Why it matters: tools/micro/mfma_coexec.hip -- while one wave streams fp32 MFMAs, vector-ALU, vector-memory
 // and LDS-read instructions of the OTHER waves of that SIMD do not issue at all, i.e. every such instruction of the K loop
 // is paid in matrix-pipe time whichever wave executes it.
-template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false, bool BNS = false>
+template <int BN, bool STEM, bool STATS, int NP, bool XH = false, bool GL = false, bool BL = false, int BNS = 0>
 __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(const void* __restrict__ Xv, const float* __restrict__ Wp,
                                               const float* __restrict__ bias, void* __restrict__ Y,
                                               double* __restrict__ stats, const void* __restrict__ addend,
@@ -697,15 +697,18 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
     // of the only consumer of y_a): its backward sums  s = sum g,  d = sum g * zhat  (g = dy_a (.) [y_a > 0], zhat = (z_a - mean)
     // * rstd; the expressions are k_bn_bwd_reduce's) are taken here, from the tile in hand and ONE read of the z_a tile, instead
     // of by a separate pass over dy_a and z_a.  Host-checked: every tile of a BNS launch is whole (the `fast` path).
+    // BNS = 1: units without residual (the ReLU mask follows from z_a's sign after the affine map); BNS = 2: a block's output
+    // unit, gated by the byte mask of its output.  Two instantiations, because the byte-mask loads cost the lean one 6 % of its
+    // time when they were a runtime branch inside it (data gradients 117.7 -> 124.6 ms/step at the headline shape).
     [[maybe_unused]] __amdgpu_buffer_rsrc_t zrs = yrs, bmrs = mrs;
     [[maybe_unused]] float4 b_m = make_float4(0, 0, 0, 0), b_r = b_m, b_sc = b_m, b_sh = b_m, b_s = b_m, b_d = b_m;
     if constexpr (BNS) {
       zrs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bn_z + tile_el), 0, y_rec, 0x00020000);
-      if (g.bn_mask)
+      if constexpr (BNS == 2)
         bmrs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bn_mask + (tile_el >> 2)), 0, hp_extent(y_el >> 2, tile_el >> 2, 1), 0x00020000);
       b_m = *(const float4*)(g.bn_mean + n0 + 4 * q_l);
       b_r = *(const float4*)(g.bn_rstd + n0 + 4 * q_l);
-      if (g.bn_relu) {
+      if (BNS == 1 && g.bn_relu) {
         const float4 ga = *(const float4*)(g.bn_gamma + n0 + 4 * q_l), be = *(const float4*)(g.bn_beta + n0 + 4 * q_l);
         b_sc = make_float4(b_r.x * ga.x, b_r.y * ga.y, b_r.z * ga.z, b_r.w * ga.w);
         b_sh = make_float4(be.x - b_m.x * b_sc.x, be.y - b_m.y * b_sc.y, be.z - b_m.z * b_sc.z, be.w - b_m.w * b_sc.w);
@@ -728,14 +731,14 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
       float4 avb[K2];
       unsigned mkb[K2];
       [[maybe_unused]] float4 zvb[BNS ? K2 : 1];
-      [[maybe_unused]] unsigned bmb[BNS ? K2 : 1];
+      [[maybe_unused]] unsigned bmb[BNS == 2 ? K2 : 1];
       if constexpr (BNS) {
 #pragma unroll
         for (int k2 = 0; k2 < K2; ++k2) {
           const int rowc = k2 * RPK;
           const unsigned so = (unsigned)(((rowc >> 5) * (C::TM * 32) + h * 32 + (rowc & 31)) * g.Nout * 4);
           zvb[k2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(zrs, vo, so, 0));
-          bmb[k2] = g.bn_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(bmrs, vo >> 4, so >> 4, 0) : 0u;
+          if constexpr (BNS == 2) bmb[k2] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(bmrs, vo >> 4, so >> 4, 0);
         }
       }
       if (fast && addend) {
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(CT, (NP == 0 && BN == 128) ? 3 : 1) void k_igemm(co
           if constexpr (BNS) {
             const float4 zz = zvb[k2];
             float4 gg = v;
-            if (g.bn_mask) {
+            if constexpr (BNS == 2) {
               const unsigned bm = bmb[k2];
               gg.x = (bm & 1u) ? v.x : 0.f;
               gg.y = (bm & 2u) ? v.y : 0.f;
@@ -3026,17 +3029,27 @@ static bool launch_igemm_bns(const IgemmGeom& g, const void* X, const float* W, 
   const bool bl = bl_on && g.Cin % 32 == 0 && (long)g.Nout * g.Cin * class_ntaps(g, 0) * 4 < (1l << 31);
   IgemmGeom gg = g;
   gg.slab = slab_on ? (int)((mt + 7) / 8) : 0;
+#define HP_BNS_LAUNCH(BN_, BL_)                                                                                                     \
+  do {                                                                                                                             \
+    if (g.bn_mask)                                                                                                                 \
+      hipLaunchKernelGGL((k_igemm<BN_, false, false, 0, false, false, BL_, 2>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr,   \
+                         addend, amask, gg);                                                                                       \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((k_igemm<BN_, false, false, 0, false, false, BL_, 1>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr,   \
+                         addend, amask, gg);                                                                                       \
+  } while (0)
   if (g.Nout <= 64) {   // one N tile of 64 columns (launch_igemm_bn's first two branches)
     const dim3 grid = gg.slab ? dim3((mt + 7) / 8 * 8, 1, 1) : dim3(mt, 1, 1);
-    if (bl) hipLaunchKernelGGL((k_igemm<64, false, false, 0, false, false, true, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
-    else hipLaunchKernelGGL((k_igemm<64, false, false, 0, false, false, false, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
+    if (bl) HP_BNS_LAUNCH(64, true);
+    else HP_BNS_LAUNCH(64, false);
     return true;
   }
   const unsigned tn = (unsigned)(g.Nout / 128);
   gg.tn = tn > 1 ? (int)tn : 0;
   const dim3 grid = (tn > 1 || gg.slab) ? dim3((mt + 7) / 8 * 8 * (tn > 1 ? tn : 1), 1, 1) : dim3(mt, 1, 1);
-  if (bl) hipLaunchKernelGGL((k_igemm<128, false, false, 0, false, false, true, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
-  else hipLaunchKernelGGL((k_igemm<128, false, false, 0, false, false, false, true>), grid, dim3(CT), 0, st, X, W, nullptr, Y, nullptr, addend, amask, gg);
+  if (bl) HP_BNS_LAUNCH(128, true);
+  else HP_BNS_LAUNCH(128, false);
+#undef HP_BNS_LAUNCH
   return true;
 }
 
