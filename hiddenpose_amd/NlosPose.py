@@ -13,6 +13,7 @@ from torch import nn
 
 from . import _lib
 from . import hip_ops as K
+from . import ranges as R
 from .feature_extraction import FeatureExtraction
 from .feature_propagation import FeaturePropagation
 from .posenet3d_50 import get_pose_net_50
@@ -50,12 +51,21 @@ class NlosPose(nn.Module):
         window = ([self.time_begin] * n, [self.time_end] * n)
         prev = K.set_dconv_precision(self.dconv_precision)  # the backward of every node uses what its forward ran with
         try:
-            feature = K.normalize_feature(self.feature_propagation(self.feature_extraction(meas), *window))
-            if isinstance(self.autoencoder, UNet3d) and self.autoencoder.in_channels == 1:
-                refine_feature, summed = self.autoencoder.forward_and_sum(feature)   # `feature + refine` in the same pass
-            else:
-                refine_feature = self.autoencoder(feature)
-                summed = K.add(feature, refine_feature)
+            # stage ranges for the profiler's marker trace (ranges.py; no-ops unless HP_ROCTX=1)
+            with R.stage("feature_extraction"):
+                feature = R.mark_backward(self.feature_extraction(meas), "feature_extraction")
+            with R.stage("feature_propagation"):
+                feature = self.feature_propagation(feature, *window)
+                feature = R.mark_backward(K.normalize_feature(feature), "feature_propagation")
+            with R.stage("autoencoder"):
+                if isinstance(self.autoencoder, UNet3d) and self.autoencoder.in_channels == 1:
+                    refine_feature, summed = self.autoencoder.forward_and_sum(feature)   # `feature + refine` in the same pass
+                else:
+                    refine_feature = self.autoencoder(feature)
+                    summed = K.add(feature, refine_feature)
+                summed = R.mark_backward(summed, "autoencoder")
         finally:
             K.set_dconv_precision(prev)
-        return self.pose_net(summed), refine_feature
+        with R.stage("pose_net"):
+            heat = R.mark_backward(self.pose_net(summed), "pose_net")
+        return heat, refine_feature

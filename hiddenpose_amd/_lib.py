@@ -29,6 +29,11 @@ SIGNATURES = {
     "hp_profile_reset": (_i, []),
     "hp_profile_count": (_i, []),
     "hp_profile_get": (_i, [_i, C.c_char_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "hp_range_enable": (_i, [_i]),
+    "hp_range_push": (_i, [C.c_char_p]),
+    "hp_range_pop": (_i, []),
+    "hp_range_start": (C.c_int64, [C.c_char_p]),
+    "hp_range_stop": (_i, [C.c_int64]),
     "hp_lct_host_constants": (_i, [_i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hp_lct_plan_create": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i]),
     "hp_lct_plan_create_mode": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i, _i]),

@@ -68,7 +68,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread"]
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -81,7 +81,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 # constant builder and the Radiance container parser, which reads UNTRUSTED file bytes) compiled by the plain host compiler
 # with AddressSanitizer + UndefinedBehaviorSanitizer into a test-only library.  tests/test_host_asan.py loads it in a child
 # process (libasan preloaded) and runs the host ABI tests and a fuzz loop against it.  No device code, no HIP runtime.
-HOST_ONLY = ["hp_error.cpp", "lct_host.cpp", "rgbe_host.cpp"]
+HOST_ONLY = ["hp_error.cpp", "lct_host.cpp", "rgbe_host.cpp", "range_host.cpp"]
 ASAN_LIB = os.path.join(OBJ, "libhiddenpose_host_asan.so")
 HOSTCXX = os.environ.get("HOSTCXX", "g++")
 
@@ -94,7 +94,7 @@ def build_asan_host(force: bool = False, verbose: bool = True) -> str:
         return ASAN_LIB
     cmd = [HOSTCXX, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
            "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
-           "-I", CSRC, "-o", ASAN_LIB] + srcs + ["-lpthread"]
+           "-I", CSRC, "-o", ASAN_LIB] + srcs + ["-lpthread", "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"host sanitizer build failed:\n{r.stdout}\n{r.stderr}")

@@ -13,6 +13,7 @@ import random
 import numpy as np
 import torch
 
+from . import ranges as R
 from .criterion import BCEDiceLoss, L2JointLocationLoss, softmax_integral_tensor
 from .optimizer import get_optimizer
 
@@ -43,10 +44,12 @@ def compute_loss(model, criterion, voxel_criterion, meas, vol, target_joints):
     """train_epoch.py:38-44.  target_joints (B,24,3) or (B,72) in heat-map voxels."""
     output, feature = model(meas)
     b = output.shape[0]
-    tj = target_joints.reshape(b, -1)
-    joint_loss = criterion(output, tj, torch.ones_like(tj))
-    voxel_loss = voxel_criterion(feature.reshape(b, -1), vol.reshape(b, -1))
-    return joint_loss + voxel_loss, joint_loss, voxel_loss, output, feature
+    with R.stage("losses"):
+        tj = target_joints.reshape(b, -1)
+        joint_loss = criterion(output, tj, torch.ones_like(tj))
+        voxel_loss = voxel_criterion(feature.reshape(b, -1), vol.reshape(b, -1))
+        loss = R.mark_backward(joint_loss + voxel_loss, "losses")
+    return loss, joint_loss, voxel_loss, output, feature
 
 
 def train_step(model, criterion, voxel_criterion, optimizer, meas, vol, target_joints, reducer=None):
@@ -57,10 +60,12 @@ def train_step(model, criterion, voxel_criterion, optimizer, meas, vol, target_j
         reducer.zero_grad()
     else:
         optimizer.zero_grad()
-    loss.backward()
-    if reducer is not None:
-        reducer.finish()
-    optimizer.step()
+    with R.stage("backward"):
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+    with R.stage("optimizer"):
+        optimizer.step()
     return loss.detach(), jl.detach(), vl.detach()
 
 

@@ -50,6 +50,20 @@ int hp_profile_reset(void);
 int hp_profile_count(void);
 int hp_profile_get(int i, char* name, int name_cap, int64_t* launches, double* total_ms);
 
+/* Stage ranges for rocprofv3's marker trace (`rocprofv3 --kernel-trace --marker-trace --stats`): SURVEY section 5's
+ * "roctx ranges per stage" -- the reference has only wall-clock prints around epochs (train_epoch.py:27-31,95-104).
+ * hp_range_enable(1) looks the marker library up at run time (librocprofiler-sdk-roctx, then libroctx64; neither is a link
+ * dependency) and returns 1 if ranges are live, 0 if the box has no such library (not an error); hp_range_enable(0)
+ * switches them off.  hp_range_push returns the calling thread's nesting depth (0 when ranges are off), hp_range_pop
+ * the depth left; push / pop pair up per thread.  hp_range_start / hp_range_stop are the thread-free form (the backward
+ * stages: autograd runs them on its own thread and the pass ends on the caller's): start returns an id > 0, or 0 when
+ * ranges are off; stop(0) is a no-op.  Host-side only: nothing is enqueued on a stream. */
+int hp_range_enable(int on);
+int hp_range_push(const char* name);
+int hp_range_pop(void);
+int64_t hp_range_start(const char* name);
+int hp_range_stop(int64_t id);
+
 /* ------------------------------------------------------------------------
  * LCT physics layer.
  * Replaces models/feature_propagation.py: LCT._parpareparam :71-109,

@@ -106,6 +106,50 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
 
 
 @pytest.mark.gpu
+def test_stage_ranges_leave_the_training_step_unchanged():
+    """SURVEY section 5 (roctx ranges per stage): with HP_ROCTX ranges live the forward carries identity marks between the
+    stages (ranges.mark_backward) and the step runs inside `backward` / `optimizer` ranges; the numbers must be those of the
+    plain step (same seeds: the only run-to-run difference is the atomics' summation order) and every range must be closed
+    when the step returns."""
+    from hiddenpose_amd import ranges as R
+    from hiddenpose_amd import testing as hpt
+    from hiddenpose_amd.config import make_cfg
+    from hiddenpose_amd.NlosPose import NlosPose
+    from hiddenpose_amd.train_epoch import build_training, compute_loss, seed_everything, train_step
+
+    def run(on):
+        live = R.enable(on)
+        seed_everything(77)
+        cfg = make_cfg(32, 16)
+        model = NlosPose(cfg).cuda().train()
+        criterion, voxel_criterion, optimizer, _ = build_training(cfg, model)
+        meas = hpt.synthetic_meas(2, 32, 16, "transient", seed=1).cuda()
+        vol = hpt.synthetic_vol(2, 32, 16, seed=2).cuda()
+        joints = hpt.synthetic_joints(2, 8, seed=3).cuda()
+        loss, _, _, out, _ = compute_loss(model, criterion, voxel_criterion, meas, vol, joints)
+        assert (type(out.grad_fn).__name__.startswith("_BackwardMark")) == bool(live)
+        loss.backward()
+        grads = {k: p.grad.double().cpu() for k, p in model.named_parameters()}
+        first = float(loss)
+        losses = [float(train_step(model, criterion, voxel_criterion, optimizer, meas, vol, joints)[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert R._bwd_open == 0 and not R._bwd_cb_queued
+        return live, first, losses, grads
+
+    try:
+        live, first_m, losses_m, grads_m = run(True)
+        if not live:
+            pytest.skip("no marker library on this box")
+        _, first_p, losses_p, grads_p = run(False)
+    finally:
+        R.enable(False)
+    assert abs(first_m - first_p) <= 1e-6 * abs(first_p) and abs(losses_m[0] - first_m) <= 1e-6 * abs(first_m)
+    assert np.allclose(losses_m, losses_p, rtol=1e-3), (losses_m, losses_p)     # the second loss has one Adam step behind it
+    worst = max(float((grads_m[k] - grads_p[k]).norm() / grads_p[k].norm().clamp_min(1e-30)) for k in grads_p)
+    assert worst < 2e-3, worst
+
+
+@pytest.mark.gpu
 def test_bf16_storage_mode_trains_like_fp32():
     """BASELINE configs[2]'s per-GPU arithmetic (`bf16s`: bf16 matrix cores, bf16 activations / activation gradients in HBM
     in the regressor; fp32 LCT, U-Net, statistics, weights and optimizer) against the fp32 mode as TRAINING, not as one step:

@@ -1,6 +1,6 @@
 """SURVEY section 5's safety net for the host code (CPU only, no device): the HIP-free translation units of the library --
-hp_error.cpp, lct_host.cpp (the LCT constant builder) and rgbe_host.cpp (the Radiance container parser, which reads
-UNTRUSTED file bytes) -- are compiled by the host compiler with -fsanitize=address,undefined
+hp_error.cpp, lct_host.cpp (the LCT constant builder), range_host.cpp (profiler stage ranges) and rgbe_host.cpp (the
+Radiance container parser, which reads UNTRUSTED file bytes) -- are compiled by the host compiler with -fsanitize=address,undefined
 (`python -m hiddenpose_amd.build --asan-host`) and exercised in a child process with the sanitizer runtime preloaded:
 the host-ABI checks of tests/test_abi_host.py, the decoder tests of tests/test_ingest.py, and a fuzz loop of truncated,
 bit-flipped and header-garbled files.  Any out-of-bounds access, overflow or misaligned / undefined operation aborts the
@@ -49,6 +49,21 @@ assert np.array_equal(r, g["T512_N128_mtx_rows"]) and np.array_equal(mtx[r, c], 
 assert L.hp_lct_host_constants(100, 16, 0.1, 2.0, None, None, None, None, None, None) == -1
 assert b"power of two" in L.hp_last_error_string()
 print("lct host constants: ok")
+
+# ---- stage ranges (range_host.cpp): off, on (if the box has a marker library), unbalanced pops, null name
+L.hp_range_start.restype = C.c_int64; L.hp_range_start.argtypes = [C.c_char_p]; L.hp_range_stop.argtypes = [C.c_int64]
+L.hp_range_push.argtypes = [C.c_char_p]
+assert L.hp_range_push(b"s") == 0 and L.hp_range_pop() == 0 and L.hp_range_start(b"s") == 0 and L.hp_range_stop(0) == 0
+assert L.hp_range_push(None) == -1
+if L.hp_range_enable(1):
+    for k in range(100):
+        assert L.hp_range_push(b"stage-%d" % k) == k + 1
+    for k in range(105):
+        L.hp_range_pop()
+    ids = [L.hp_range_start(b"x" * (k + 1)) for k in range(50)]
+    for i in ids: L.hp_range_stop(i)
+L.hp_range_enable(0)
+print("stage ranges: ok")
 
 # ---- Radiance container decoder
 def decode(data, cap_limit=1 << 26):
