@@ -3166,9 +3166,35 @@ static WgradSplit wgrad_split(const ConvPlan& p) {
   const int tiles_n = (g.Nout + w.TT - 1) / w.TT;
   w.tiles_c = (Kc + w.TT - 1) / w.TT;
   const long base_blocks = (long)tiles_n * w.tiles_c * w.tap_groups;
-  long msplit = std::max<long>(1, (4096 + base_blocks - 1) / base_blocks);
-  msplit = std::min<long>(msplit, std::max<long>(1, g.M / (4 * WG_KM)));
-  w.msplit = std::min<long>(msplit, 4096);
+  // Upper end: ~4096 blocks (the large layers: plenty of rows per block, and many short blocks balance best), at least 4
+  // steps per block.  Below it, the count that minimises  waves x (rows per block + R0):  every block pays a fixed price --
+  // prologue, and TT x TT fp32 atomics in the epilogue -- worth R0 rows of its main loop (fitted on layers 3 / 4 of the
+  // bench shape: ~96 rows with fp32 operands, ~768 with bf16 ones, whose rows are five times cheaper; 768 resident blocks).
+  // With M = 8192 ... 65536 rows the old rule alone cut 4096 blocks of 128 ... 256 rows: layer 4's 1^3 weight gradients
+  // ran 0.235 ms (fp32) / 0.211 ms (bf16s) against 0.157 / 0.055 with a sixth of the blocks (round 4).
+  long hi = std::max<long>(1, (4096 + base_blocks - 1) / base_blocks);
+  hi = std::min<long>(std::min<long>(hi, std::max<long>(1, g.M / (4 * WG_KM))), 4096);
+  static const int fixed_env = getenv("HP_WGRAD_R0") ? atoi(getenv("HP_WGRAD_R0")) : -1;   // 0: the old rule
+  const long r0 = fixed_env >= 0 ? fixed_env : ((g.xh && g.yh) ? 768 : 96);
+  long best = hi;
+  if (r0 > 0) {
+    const long slots = 768;
+    auto cost = [&](long ms) {
+      const long rows = ((g.M + ms - 1) / ms + WG_KM - 1) / WG_KM * WG_KM;
+      const long blocks = base_blocks * ms;
+      double c = (double)((blocks + slots - 1) / slots) * (double)(rows + r0);
+      if (blocks & 7) c *= 1.02;   // the XCD renumbering of the kernels needs a grid that is a multiple of 8
+      return c;
+    };
+    double cmin = cost(hi);
+    for (long ms = 1; ms < hi; ++ms) cmin = std::min(cmin, cost(ms));
+    for (long ms = hi; ms >= 1; --ms)   // the largest count within 3 % of the minimum: more, shorter blocks balance better
+      if (cost(ms) <= 1.03 * cmin) {
+        best = ms;
+        break;
+      }
+  }
+  w.msplit = best;
   w.tiles_total = tiles_n * w.tiles_c;
   return w;
 }
@@ -3178,6 +3204,8 @@ extern "C" int hp_conv3d_backward_weight_split(const hp_conv_desc* d, long* mspl
   ConvPlan p;
   int rc = make_plan(*d, p);
   if (rc) return rc;
+  p.wgrad.xh = (d->io & HP_IO_X_BF16) ? 1 : 0;   // as hp_conv3d_backward_weight sets them: the split depends on the operand type
+  p.wgrad.yh = (d->io & HP_IO_DY_BF16) ? 1 : 0;
   const WgradSplit ws = wgrad_split(p);
   *msplit = ws.msplit;
   *chunk_rows = ((p.wgrad.M + ws.msplit - 1) / ws.msplit + WG_KM - 1) / WG_KM * WG_KM;  // as the kernels round it

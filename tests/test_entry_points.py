@@ -145,8 +145,12 @@ def test_stage_ranges_leave_the_training_step_unchanged():
         R.enable(False)
     assert abs(first_m - first_p) <= 1e-6 * abs(first_p) and abs(losses_m[0] - first_m) <= 1e-6 * abs(first_m)
     assert np.allclose(losses_m, losses_p, rtol=1e-3), (losses_m, losses_p)     # the second loss has one Adam step behind it
-    worst = max(float((grads_m[k] - grads_p[k]).norm() / grads_p[k].norm().clamp_min(1e-30)) for k in grads_p)
-    assert worst < 2e-3, worst
+    # per parameter, against its own norm; gradients that are pure rounding noise in both runs (a convolution bias in front of a
+    # normalisation: exactly zero in exact arithmetic) are measured against the largest gradient of the net instead
+    top = max(float(g.norm()) for g in grads_p.values())
+    bad = {k: (float((grads_m[k] - grads_p[k]).norm()), float(grads_p[k].norm())) for k in grads_p
+           if float((grads_m[k] - grads_p[k]).norm()) > 2e-3 * float(grads_p[k].norm()) + 1e-6 * top}
+    assert not bad, (top, bad)
 
 
 @pytest.mark.gpu
