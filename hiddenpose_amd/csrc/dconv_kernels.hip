@@ -1902,7 +1902,8 @@ static int run_dconv(const float* x, const float* w, const float* bias, const fl
              Hi, Wi);
   const int tiles_x = (Wo + WG_TX - 1) / WG_TX, tiles_y = (Ho + WG_TY - 1) / WG_TY, cog_n = (cout + 3) / 4;
   const long cols = (long)tiles_x * tiles_y * B * cog_n;
-  int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (1536 + cols - 1) / cols));
+  static const long blocks_target = getenv("HP_DCONV_BLOCKS") ? atol(getenv("HP_DCONV_BLOCKS")) : 1536;
+  int zsplit = (int)std::max<long>(1, std::min<long>((Do + 7) / 8, (blocks_target + cols - 1) / cols));
   const int zchunk = (Do + zsplit - 1) / zsplit;
   zsplit = (Do + zchunk - 1) / zchunk;
   dim3 grid((unsigned)(tiles_x * tiles_y * zsplit), (unsigned)B, (unsigned)cog_n);
@@ -2082,10 +2083,15 @@ WgradGeom wgrad_geom(int B, int cin, int cout, int D, int H, int W) {
   q.cig_n = (cin + 3) / 4;
   q.tiles_x = (W + hp::WG_TX - 1) / hp::WG_TX;
   q.tiles_y = (H + hp::WG_TY - 1) / hp::WG_TY;
-  // z range per workgroup: ~1024 workgroups (2 resident per CU), at least 8 planes each: 2 halo planes are
-  // re-read and one 448-value reduction is paid per chunk
+  // z range per workgroup: ~512 workgroups = ONE resident wave of 2 per CU (1024 for the single-channel kernel), at least 8
+  // planes each: 2 halo planes are re-read, and a partial tile is written and reduced per workgroup.  Sweep at the U-Net shapes
+  // of 1024 x 256 x 256 and 512 x 128 x 128 (gpurun_out/r4/dblocks*.log): 256 / 384 / 512 / 768 / 1024 / 1536 workgroups ->
+  // layer sums 6.74 / 6.01 / 5.19 / 5.41 / 5.05 / 5.25 ms and 1.16 / 1.17 / 0.98 / 1.10 / 1.08 / 1.15 ms: whole waves win, and among
+  // them the fewest (round 4; 1024 before)
   const long cols = (long)q.tiles_x * q.tiles_y * B * q.cog_n * q.cig_n;
-  q.zsplit = (int)std::max<long>(1, std::min<long>((D + 7) / 8, (1024 + cols - 1) / cols));
+  static const long blocks_env = getenv("HP_DCONV_WBLOCKS") ? atol(getenv("HP_DCONV_WBLOCKS")) : 0;
+  const long blocks_target = blocks_env > 0 ? blocks_env : (cin == 1 && cout == 1) ? 1024 : 512;
+  q.zsplit = (int)std::max<long>(1, std::min<long>((D + 7) / 8, (blocks_target + cols - 1) / cols));
   q.zchunk = (D + q.zsplit - 1) / q.zsplit;
   q.zsplit = (D + q.zchunk - 1) / q.zchunk;
   q.nwg = (long)q.tiles_x * q.tiles_y * q.zsplit * B;
