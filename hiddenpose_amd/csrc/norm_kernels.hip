@@ -1009,8 +1009,18 @@ __global__ __launch_bounds__(ET) void k_cast(const void* __restrict__ x, int x_h
   for (long i = (long)blockIdx.x * ET + threadIdx.x; i < n4; i += (long)gridDim.x * ET) hp_st4(y, 4 * i, hp_ld4(x, 4 * i, x_half), y_half);
 }
 
+// Grid of the streaming BatchNorm passes (grid-stride loops over channel quads): THREE workgroups per CU.  Round 4 sweep at the
+// headline shape (per step, un-overlapped): forward apply 18.7 ms with 2048 workgroups (8 per CU: rounds 1-3), 17.5 with 1024,
+// 16.9 with 768, 17.6 with 512, 17.8 / 17.6 with 640 / 896; backward apply 23.7 / 22.6 / 21.7 / 21.4 with 2048 / 1024 / 768 / 512
+// -- fewer concurrent streams, and every CU with the same number of them.  (The planar U-Net / GroupNorm / pooling passes do
+// not care: 2048 stays there.)  HP_BN_GRID / HP_BN_BWD_GRID: A/B hooks.
 static unsigned grid_for(long n, int per_block = ET) {
-  return (unsigned)std::min<long>((n + per_block - 1) / per_block, 256 * 8);
+  static const long cap = getenv("HP_BN_GRID") ? atol(getenv("HP_BN_GRID")) : 256 * 3;
+  return (unsigned)std::min<long>((n + per_block - 1) / per_block, cap);
+}
+static unsigned grid_for_bwd(long n, int per_block = ET) {   // the backward apply passes
+  static const long cap = getenv("HP_BN_BWD_GRID") ? atol(getenv("HP_BN_BWD_GRID")) : 256 * 3;
+  return (unsigned)std::min<long>((n + per_block - 1) / per_block, cap);
 }
 
 // IOM of QIO for a call: 0 = every tensor fp32, 1 = every tensor bf16 (and an even number of channel quads), 2 = mixed
@@ -1143,16 +1153,16 @@ extern "C" int hp_bn_backward(const void* dy, const float* y, const void* z, voi
     const long n4 = M * C4;
     if (bytemask) {
       const int iom = io_mode(C4, {dy_half, z_half, dz_half});
-      HP_LAUNCH_IOM(k_bn_bwd_apply_bytemask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+      HP_LAUNCH_IOM(k_bn_bwd_apply_bytemask, iom, grid_for_bwd(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
                     (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
     } else if (remask) {
       const int iom = io_mode(C4, {dy_half, z_half, dz_half});
-      HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+      HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for_bwd(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
                     (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean, (const float4*)rstd,
                     (const float4*)gamma, (const float4*)beta_for_mask, relu);
     } else {
       const int iom = io_mode(C4, {z_half, dz_half});
-      HP_LAUNCH_IOM(k_bn_bwd_apply, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, (const void*)gbuf, dz_half, z, z_half, dz, dz_half, n4,
+      HP_LAUNCH_IOM(k_bn_bwd_apply, iom, grid_for_bwd(n4 / (iom == 1 ? 2 : 1)), st, (const void*)gbuf, dz_half, z, z_half, dz, dz_half, n4,
                     C4, (const float4*)ca, (const float4*)cb, (const float4*)cc);
     }
   }
@@ -1190,10 +1200,10 @@ extern "C" int hp_bn_backward_presummed(const void* dy, const void* z, void* dz,
     const long n4 = M * C4;
     const int iom = io_mode(C4, {dy_half, z_half, dz_half});
     if (relu && relu_mask)
-      HP_LAUNCH_IOM(k_bn_bwd_apply_bytemask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+      HP_LAUNCH_IOM(k_bn_bwd_apply_bytemask, iom, grid_for_bwd(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
                     (const float4*)ca, (const float4*)cb, (const float4*)cc, relu_mask);
     else
-      HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
+      HP_LAUNCH_IOM(k_bn_bwd_apply_mask, iom, grid_for_bwd(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, z, z_half, dz, dz_half, n4, C4,
                     (const float4*)ca, (const float4*)cb, (const float4*)cc, (const float4*)mean, (const float4*)rstd,
                     (const float4*)gamma, (const float4*)beta_for_mask, relu);
   }
@@ -1235,7 +1245,7 @@ extern "C" int hp_bn_backward_dual(const void* dy, const unsigned char* relu_mas
     HP_PROF("bn_bwd_apply", st);
     const long n4 = M * C4;
     const int iom = io_mode(C4, {dy_half, z_half, dz_half});
-    HP_LAUNCH_IOM(k_bn_bwd_apply_dual, iom, grid_for(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, relu_mask, z_a, z_b, z_half, dz_a, dz_b,
+    HP_LAUNCH_IOM(k_bn_bwd_apply_dual, iom, grid_for_bwd(n4 / (iom == 1 ? 2 : 1)), st, dy, dy_half, relu_mask, z_a, z_b, z_half, dz_a, dz_b,
                   dz_half, n4, C4, (const float4*)ca_a, (const float4*)cb_a, (const float4*)cc_a, (const float4*)ca_b,
                   (const float4*)cb_b, (const float4*)cc_b);
   }
