@@ -1128,11 +1128,13 @@ extern "C" int hp_bn_backward(const void* dy, const float* y, const void* z, voi
                       : gbuf ? io_mode(C4, {dy_half, z_half, dz_half}) : io_mode(C4, {dy_half, z_half});
     const int CG = C4 / (iom == 1 ? 2 : 1);
     const int rows_per_pass = CG < ET ? ET / CG : 1;
-    // at most two workgroups per CU, and at least HP_BN_RED_TRIPS (default 16) trips of 4 rows per thread: a workgroup's fixed
+    // at most one workgroup per CU, and at least HP_BN_RED_TRIPS (default 16) trips of 4 rows per thread: a workgroup's fixed
     // cost (parameter loads, the cross-row reduction, 2C fp64 atomics) is paid per workgroup, and on the small tensors of the
     // deep layers a grid sized by rows alone spends most of its time there
     static const int trips_min = getenv("HP_BN_RED_TRIPS") ? atoi(getenv("HP_BN_RED_TRIPS")) : 16;
-    const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(M / ((long)rows_per_pass * 4 * trips_min), 256 * 2));
+    // (one workgroup per CU since round 4: 8.66 ms/step at the headline shape against 9.2 with two, 9.1 with three, 9.7 with four)
+    static const long red_wgs = getenv("HP_BN_RED_WGS") ? atol(getenv("HP_BN_RED_WGS")) : 256;
+    const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(M / ((long)rows_per_pass * 4 * trips_min), red_wgs));
     if (iom == 0)
       hipLaunchKernelGGL((k_bn_bwd_reduce<4, 0>), dim3(nb), dim3(ET), 0, st, dy, dy_half, (const float4*)y, z, z_half, gbuf, dz_half, M,
                          C4, (const float4*)mean, (const float4*)rstd, relu, red, (const float4*)gamma, (const float4*)beta_for_mask,
@@ -1302,7 +1304,9 @@ extern "C" int hp_stem_bn_relu_pool_forward(const float* z, float* pooled, int B
   hipLaunchKernelGGL(k_bn_scale_shift, dim3((C + 127) / 128), dim3(128), 0, st, mean, rstd, gamma, beta, C, sc, sh);
   HP_PROF("stem_bn_relu_pool_fwd", st);
   const long n = (long)B * (D / 2) * (H / 2) * (W / 2) * (C / 4);
-  const unsigned grid = grid_for(n);
+  // two workgroups per CU: 2.28 ms at the headline shape against 2.50 with eight and 2.88 with three (768 x 256 threads does not
+  // divide the pooled tensor, which costs the slab order below)
+  const unsigned grid = (unsigned)std::min<long>((n + ET - 1) / ET, 256 * 2);
   // slab order (each XCD walks a contiguous eighth of the pooled tensor) when the launch is whole rounds and the extents
   // decode with shifts; otherwise runs of 32 chunks per XCD and round, or the plain order.  HP_POOL_XCD_SLAB=0: plain (A/B runs)
   static const bool xslab = !(getenv("HP_POOL_XCD_SLAB") && atoi(getenv("HP_POOL_XCD_SLAB")) == 0);
@@ -1353,7 +1357,9 @@ extern "C" int hp_stem_bn_relu_pool_backward(const float* z, const float* pooled
                      ca, cb, cc);
   if (tiled) {
     HP_PROF("stem_bn_pool_bwd_apply", st);
-    hipLaunchKernelGGL(k_stem_bwd_tiled<true>, dim3((unsigned)std::min<long>(ntiles, 256 * 64)), dim3(ET), 0, st, (const float4*)z,
+    // (eight workgroups per CU: 3.66 ms at the headline shape against 3.9-4.0 with 64 per CU, 3.8 with four, 4.6 with two)
+    static const long stem_apply_cap = getenv("HP_STEM_APPLY_GRID") ? atol(getenv("HP_STEM_APPLY_GRID")) : 256 * 8;
+    hipLaunchKernelGGL(k_stem_bwd_tiled<true>, dim3((unsigned)std::min<long>(ntiles, stem_apply_cap)), dim3(ET), 0, st, (const float4*)z,
                        (const float4*)pooled, (const float4*)dpooled, (float4*)dz, B, D, H, W, (const float4*)sc, (const float4*)sh,
                        (const float4*)ca, (const float4*)cb, (const float4*)cc, (double*)nullptr, ntiles, xslab);
   } else {
