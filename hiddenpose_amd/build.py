@@ -24,7 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-          "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics"]
+          "-Wall", "-Wno-unused-function", "-munsafe-fp-atomics"] + os.environ.get("HP_EXTRA_DEFS", "").split()   # A/B builds
 
 
 def _sources():

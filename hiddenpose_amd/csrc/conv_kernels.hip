@@ -3194,6 +3194,13 @@ static WgradSplit wgrad_split(const ConvPlan& p) {
         break;
       }
   }
+  // the kernels round a chunk up to whole steps of WG_KM rows: drop the chunks that this rounding leaves empty
+  for (;;) {
+    const long chunk = ((g.M + best - 1) / best + WG_KM - 1) / WG_KM * WG_KM;
+    const long need = (g.M + chunk - 1) / chunk;
+    if (need >= best) break;
+    best = need;
+  }
   w.msplit = best;
   w.tiles_total = tiles_n * w.tiles_c;
   return w;

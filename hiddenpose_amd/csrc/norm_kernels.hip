@@ -17,6 +17,48 @@ constexpr int ET = 256;
 #define HP_BN_UNR_H 8
 #endif
 
+// Streaming hints (round 4): the BatchNorm passes read and write every activation tensor exactly once -- tens of GB per step
+// that displace the operands the weight gradients on the other stream re-read through L2 / MALL.  Their 16-byte accesses carry
+// the non-temporal bit (`global_load_dwordx4 ... nt`): same-box A/B/A/B at the headline shape 468.7 / 469.9 -> 466.9 / 466.8
+// ms/step, and the passes themselves are not slower alone (apply 16.9 -> 16.3, reduce 8.5 -> 8.2 ms/step).  -DHP_BN_NT=0
+// (HP_EXTRA_DEFS, hiddenpose_amd/build.py) builds without it.  Not for the stem's pool kernels: their windows overlap and
+// live on L2 reuse.
+#ifndef HP_BN_NT
+#define HP_BN_NT 1
+#endif
+typedef float hp_f4v __attribute__((ext_vector_type(4)));
+typedef unsigned hp_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if HP_BN_NT
+  const hp_f4v t = __builtin_nontemporal_load(reinterpret_cast<const hp_f4v*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+#if HP_BN_NT
+  const hp_u4v t = __builtin_nontemporal_load(reinterpret_cast<const hp_u4v*>(p));
+  return make_uint4(t.x, t.y, t.z, t.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if HP_BN_NT
+  __builtin_nontemporal_store((hp_f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<hp_f4v*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+#if HP_BN_NT
+  __builtin_nontemporal_store((hp_u4v){v.x, v.y, v.z, v.w}, reinterpret_cast<hp_u4v*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // Element-type plumbing of the BatchNorm passes.  IOM = 0: every tensor fp32, IOM = 1: every tensor bf16 -- both known
 // at compile time, so a pass issues all its loads back to back (a run-time type test per access put a conversion, and
 // with it a wait, between consecutive loads: the bf16 reduce pass ran SLOWER than the fp32 one) -- and a lane moves
@@ -26,9 +68,9 @@ struct QIO {
   static constexpr int Q = IOM == 1 ? 2 : 1;
   static __device__ __forceinline__ void ld(const void* p, long g, int half, float4 (&o)[Q]) {  // group g = quads g*Q ..
     if constexpr (IOM == 0) {
-      o[0] = *(reinterpret_cast<const float4*>(p) + g);
+      o[0] = ld_stream(reinterpret_cast<const float4*>(p) + g);
     } else if constexpr (IOM == 1) {
-      const uint4 u = *(reinterpret_cast<const uint4*>(p) + g);
+      const uint4 u = ld_stream(reinterpret_cast<const uint4*>(p) + g);
       o[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                          __uint_as_float(u.y & 0xffff0000u));
       o[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
@@ -39,14 +81,14 @@ struct QIO {
   }
   static __device__ __forceinline__ void st(void* p, long g, const float4 (&v)[Q], int half) {
     if constexpr (IOM == 0) {
-      *(reinterpret_cast<float4*>(p) + g) = v[0];
+      st_stream(reinterpret_cast<float4*>(p) + g, v[0]);
     } else if constexpr (IOM == 1) {
       typedef __attribute__((ext_vector_type(2))) float f2;
       typedef __attribute__((ext_vector_type(2))) __bf16 h2;
       const h2 a = __builtin_convertvector((f2){v[0].x, v[0].y}, h2), b = __builtin_convertvector((f2){v[0].z, v[0].w}, h2);
       const h2 c = __builtin_convertvector((f2){v[1].x, v[1].y}, h2), d = __builtin_convertvector((f2){v[1].z, v[1].w}, h2);
-      *(reinterpret_cast<uint4*>(p) + g) = make_uint4(__builtin_bit_cast(unsigned int, a), __builtin_bit_cast(unsigned int, b),
-                                                      __builtin_bit_cast(unsigned int, c), __builtin_bit_cast(unsigned int, d));
+      st_stream(reinterpret_cast<uint4*>(p) + g, make_uint4(__builtin_bit_cast(unsigned int, a), __builtin_bit_cast(unsigned int, b),
+                                                           __builtin_bit_cast(unsigned int, c), __builtin_bit_cast(unsigned int, d)));
     } else {
       hp_st4(p, 4 * g, v[0], half);
     }
@@ -922,9 +964,9 @@ __global__ __launch_bounds__(ET) void k_stem_bwd_tiled(const float4* __restrict_
       g.w = y.w > 0.f ? g.w : 0.f;
       const float4 v = zv[it];
       if constexpr (APPLY) {
-        dz[((((long)b * D + d) * H + h) * W + w) * C4 + cq] =
-            make_float4(fmaf(q0.x, g.x, fmaf(q1.x, v.x, q2.x)), fmaf(q0.y, g.y, fmaf(q1.y, v.y, q2.y)),
-                        fmaf(q0.z, g.z, fmaf(q1.z, v.z, q2.z)), fmaf(q0.w, g.w, fmaf(q1.w, v.w, q2.w)));
+        st_stream(dz + ((((long)b * D + d) * H + h) * W + w) * C4 + cq,
+                  make_float4(fmaf(q0.x, g.x, fmaf(q1.x, v.x, q2.x)), fmaf(q0.y, g.y, fmaf(q1.y, v.y, q2.y)),
+                              fmaf(q0.z, g.z, fmaf(q1.z, v.z, q2.z)), fmaf(q0.w, g.w, fmaf(q1.w, v.w, q2.w))));
       } else {
         s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
         dd.x += g.x * (v.x - q0.x) * q1.x;
