@@ -3177,7 +3177,22 @@ static WgradSplit wgrad_split(const ConvPlan& p) {
   static const int fixed_env = getenv("HP_WGRAD_R0") ? atoi(getenv("HP_WGRAD_R0")) : -1;   // 0: the old rule
   const long r0 = fixed_env >= 0 ? fixed_env : ((g.xh && g.yh) ? 768 : 96);
   long best = hi;
-  if (r0 > 0) {
+  // (the search below is a few thousand cost evaluations: remembered per (M, blocks, R0) -- a training loop asks for the same
+  // ~60 geometries every step)
+  struct Memo { long M, base, r0, hi, best; };
+  static std::mutex memo_mu;
+  static std::vector<Memo> memo;
+  bool known = false;
+  {
+    std::lock_guard<std::mutex> lk(memo_mu);
+    for (const Memo& m : memo)
+      if (m.M == g.M && m.base == base_blocks && m.r0 == r0 && m.hi == hi) {
+        best = m.best;
+        known = true;
+        break;
+      }
+  }
+  if (r0 > 0 && !known) {
     const long slots = 768;
     auto cost = [&](long ms) {
       const long rows = ((g.M + ms - 1) / ms + WG_KM - 1) / WG_KM * WG_KM;
@@ -3195,11 +3210,15 @@ static WgradSplit wgrad_split(const ConvPlan& p) {
       }
   }
   // the kernels round a chunk up to whole steps of WG_KM rows: drop the chunks that this rounding leaves empty
-  for (;;) {
+  for (; !known;) {
     const long chunk = ((g.M + best - 1) / best + WG_KM - 1) / WG_KM * WG_KM;
     const long need = (g.M + chunk - 1) / chunk;
     if (need >= best) break;
     best = need;
+  }
+  if (!known) {
+    std::lock_guard<std::mutex> lk(memo_mu);
+    if (memo.size() < 4096) memo.push_back({g.M, base_blocks, r0, hi, best});
   }
   w.msplit = best;
   w.tiles_total = tiles_n * w.tiles_c;
