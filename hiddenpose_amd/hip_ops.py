@@ -720,6 +720,8 @@ def bn_link():
 # describes a contended launch, so bench.py times the step with the overlap and takes its per-kernel table / roofline from
 # appended steps with the mode switched off.
 _WGRAD_ASYNC = bool(int(__import__("os").environ.get("HP_WGRAD_STREAM", "1")))
+_WGRAD_SIDE_MODE = int(__import__("os").environ.get("HP_WGRAD_SIDE_MODE", "3"))
+_WGRAD_SIDE_MB = int(__import__("os").environ.get("HP_WGRAD_SIDE_MB", "512"))
 _side_streams = {}
 _joined_task = [-1]
 # Which top-level forward a weight's use count belongs to: `begin_forward()` (called by the regressor's forward) opens a new
@@ -829,6 +831,17 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=No
     desc.io &= ~HP_IO_W
     n = int(L.hp_conv3d_packed_weight_elems(_C.byref(desc)))
     side = _wgrad_side_stream(x.device)
+    if side is not None and _WGRAD_SIDE_MODE != 1:
+        # Which weight gradients take the second stream (HP_WGRAD_SIDE_MODE; 1 = all of them: rounds 3-4): the convolutions WITH
+        # taps (k > 1) -- their weight gradients are matrix-core-bound and re-read their operands through L2, so the memory-bound
+        # passes of backward's critical path really run in their shadow -- and (mode 3, the default) the 1^3 layers whose operands
+        # are small (x + dz below HP_WGRAD_SIDE_MB).  A LARGE 1^3 weight gradient reads x and dz exactly once at 2+ TB/s: next to
+        # a BatchNorm pass that wants all of HBM the two only slow each other down.  Same box, 10 steps, twice each, headline
+        # shape: all 457.7 / 457.9, mode 2 455.6 / 454.2, mode 3 454.9 / 455.0, one stream 455.7 / 455.6 ms/step; bf16s and the
+        # 128^3 shape: 148.6-148.7 and 125.8-126.1 in every mode (one stream: 151.7 / 127.7).
+        big = (x.numel() * x.element_size() + dz.numel() * dz.element_size()) >= (_WGRAD_SIDE_MB << 20)
+        if desc.k == 1 and (_WGRAD_SIDE_MODE == 2 or big):
+            side = None
     if side is not None:
         # The side-stream hand-over is safe only where nothing reads `dw` on the main stream before the join: a leaf whose
         # gradient autograd merely adopts (or that we accumulate ourselves, below).  A tensor hook receives the gradient, a
