@@ -761,7 +761,9 @@ def main():
             "config": {"workload": f"NlosPose train step (fwd+L2Joint+BCEDice loss+bwd+Adam), {N}x{N}x{T} transients, "
                                    f"batch {B}/GPU, " + (f"{args.conv_precision} convolutions (bf16 matrix cores, {mfma_terms} plane product(s), fp32 "
                                    "accumulation) with fp32 LCT, U-Net, norms, losses and " + ("bf16 regressor activations / activation gradients in HBM (fp32 raw conv outputs, statistics, weights)" if args.conv_precision == "bf16s" else "fp32 tensors in HBM") if bf16 else "fp32") + ", random-init weights"
-                                   + (", weight gradients on a second stream" if wgrad_stream else ", weight gradients on the main stream"),
+                                   + ((", weight gradients on a second stream" if _ops._WGRAD_SIDE_MODE == 1 else
+                                       ", weight gradients of the 3^3 / 4^3 convolutions (and of small 1^3 ones) on a second stream")
+                                      if wgrad_stream else ", weight gradients on the main stream"),
                        "global_batch": B * world, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": args.dp_algo if reducer_on else None, "ranks": ranks_seen,
