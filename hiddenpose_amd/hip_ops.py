@@ -54,6 +54,7 @@ def set_dconv_precision(name: str) -> str:
 # randomly filled network amplifies the operand rounding itself.
 _DCONV_NAMES = ("fp32", "bf16", "bf16emu")
 # A/B switch: HP_DCONV_WGRAD_BF16=0 keeps the weight gradients of the bf16 mode on the exact kernel
+_DCONV_WGRAD_STREAM = bool(int(__import__("os").environ.get("HP_DCONV_WGRAD_STREAM", "1")))   # thin-channel weight gradients on the second stream
 _DCONV_WGRAD_BF16 = os.environ.get("HP_DCONV_WGRAD_BF16", "1") != "0"
 
 
@@ -61,7 +62,7 @@ def _emu(t, prec, cin, cout):
     return t.bfloat16().float() if prec == 2 and not (cin == 1 and cout == 1) else t
 
 
-def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0):
+def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0, w_param=None, b_param=None):
     """(dx, dw, db) of y = conv3(x, w) + b given g = dL/dy; planar tensors."""
     L = _lib.lib()
     b, cin, d, h, wd = x.shape
@@ -86,8 +87,25 @@ def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0):
     wprec = prec if _DCONV_WGRAD_BF16 else 0
     emu_w = wprec == 2 and cin > 1 and wd % 4 == 0   # the layers the bf16 weight-gradient kernel takes (others run exact)
     xe, ge = (x.bfloat16().float(), g.bfloat16().float()) if emu_w else (x, g)
-    _lib.check(L.hp_dconv3_backward_weight_p(xe.data_ptr(), ge.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
-                                             d, h, wd, rp, wprec & 1, wsw.data_ptr(), st), "hp_dconv3_backward_weight_p")
+    # The weight gradient has no reader before the optimizer: second stream, as the regressor's (see _conv_grads for the
+    # allocation / lifetime rules: outputs allocated here on the main stream and not held, operands held until the main stream has
+    # waited for the kernel).  Only the plain case: leaf parameters without hooks whose .grad autograd will simply adopt.
+    side = _wgrad_side_stream(x.device) if (_DCONV_WGRAD_STREAM and w_param is not None) else None
+    if side is not None:
+        ps = [w_param] + ([b_param] if b_param is not None else [])
+        if any((not q.is_leaf) or q.grad is not None or getattr(q, "_backward_hooks", None) or
+               getattr(q, "_post_accumulate_grad_hooks", None) for q in ps):
+            side = None
+    if side is None:
+        _lib.check(L.hp_dconv3_backward_weight_p(xe.data_ptr(), ge.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
+                                                 d, h, wd, rp, wprec & 1, wsw.data_ptr(), st), "hp_dconv3_backward_weight_p")
+        return gx, dw, db
+    main = torch.cuda.current_stream(x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _lib.check(L.hp_dconv3_backward_weight_p(xe.data_ptr(), ge.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
+                                                 d, h, wd, rp, wprec & 1, wsw.data_ptr(), _stream(x)), "hp_dconv3_backward_weight_p")
+    _hold(x.device, side, main, (xe, ge, wsw))
     return gx, dw, db
 
 
@@ -116,6 +134,7 @@ class _DConv3(torch.autograd.Function):
             ctx.save_for_backward(x, w)
         ctx.cfg = (replicate, bias is not None, res is not None, float(slope))
         ctx.prec = _DCONV_PRECISION
+        ctx.bias_ref = bias     # (the parameter itself, for the side-stream test of its backward; not a saved tensor: no version check)
         return y
 
     @staticmethod
@@ -132,7 +151,7 @@ class _DConv3(torch.autograd.Function):
             x, w = ctx.saved_tensors
             g = gy
         with torch.cuda.device(x.device):
-            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0], ctx.prec)
+            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0], ctx.prec, w, ctx.bias_ref)
         return gx, dw, db, None, (g if has_res else None), None
 
 
@@ -171,6 +190,7 @@ class _ConvGnRelu(torch.autograd.Function):
         ctx.save_for_backward(x, w, z, gamma, mean, rstd, aff)
         ctx.cfg = (groups, bias is not None)
         ctx.prec = _DCONV_PRECISION
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -190,7 +210,7 @@ class _ConvGnRelu(torch.autograd.Function):
                                                        gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), aff[0].data_ptr(),
                                                        aff[1].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                                                        _stream(z)), "hp_groupnorm_relu_backward_v2")
-            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0], ctx.prec)
+            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0], ctx.prec, w, ctx.bias_ref)
         return gx, dw, db, dgamma, dbeta, None, None, None
 
 

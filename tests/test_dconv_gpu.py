@@ -171,3 +171,38 @@ def test_conv_groupnorm_relu_one_node(cin, cout, dims):
     scale = float(gy.abs().sum()) * float(gamma.abs().max())
     assert float((bg.grad.cpu().double() - bd.grad).abs().max()) < 1e-6 * scale
     assert rel_l2(gg.grad, gd.grad) < 2e-5 and rel_l2(btg.grad, btd.grad) < 2e-5
+
+
+@pytest.mark.gpu
+def test_thin_channel_weight_gradients_on_the_second_stream_equal_the_serial_ones():
+    """Round 4: the thin-channel weight gradients (FeatureExtraction / U-Net) run on the second stream like the regressor's
+    (hip_ops._dconv3_grads): leaf parameters whose .grad autograd simply adopts; operands held until the main stream has waited
+    for the kernel; joined when backward ends.  Same kernels, same order of summation: the gradients are bit-equal to the
+    one-stream run -- also with a parameter that already holds a gradient (accumulation: that layer stays on the main stream)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 4, 12, 16, 64, generator=g).cuda()
+    ws = [(torch.randn(8, 4, 3, 3, 3, generator=g) * 0.2).cuda(), (torch.randn(4, 8, 3, 3, 3, generator=g) * 0.2).cuda()]
+    bs = [torch.randn(8, generator=g).cuda(), torch.randn(4, generator=g).cuda()]
+    gam, bet = (1 + 0.3 * torch.randn(8, generator=g)).cuda(), (0.3 * torch.randn(8, generator=g)).cuda()
+    gy = torch.randn(2, 4, 12, 16, 64, generator=g).cuda()
+
+    def run(on, pre_grad):
+        prev = ops._DCONV_WGRAD_STREAM
+        ops._DCONV_WGRAD_STREAM = on
+        try:
+            ps = [t.clone().requires_grad_(True) for t in (ws[0], bs[0], gam, bet, ws[1], bs[1])]
+            if pre_grad:
+                ps[4].grad = torch.full_like(ps[4], 0.5)
+            xi = x.clone().requires_grad_(True)
+            for _ in range(2):          # twice: the hold queue and the end-of-backward join are exercised across passes
+                y = ops._DConv3.apply(ops.conv3_gn_relu(xi, ps[0], ps[1], ps[2], ps[3], 4, 1e-5), ps[4], ps[5], False, xi, 0.2)
+                (y * gy).sum().backward()
+            torch.cuda.synchronize()
+            return [xi.grad.clone()] + [p.grad.clone() for p in ps]
+        finally:
+            ops._DCONV_WGRAD_STREAM = prev
+
+    for pre in (False, True):
+        a, b = run(True, pre), run(False, pre)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
