@@ -49,6 +49,7 @@ class NlosPose(nn.Module):
     def forward(self, meas):
         n = meas.shape[0]
         window = ([self.time_begin] * n, [self.time_end] * n)
+        K.begin_forward()   # per-weight use counts of the side-stream weight gradients belong to THIS forward (hip_ops)
         prev = K.set_dconv_precision(self.dconv_precision)  # the backward of every node uses what its forward ran with
         try:
             # stage ranges for the profiler's marker trace (ranges.py; no-ops unless HP_ROCTX=1)

@@ -62,6 +62,50 @@ def _emu(t, prec, cin, cout):
     return t.bfloat16().float() if prec == 2 and not (cin == 1 and cout == 1) else t
 
 
+_side_dconv_calls = [0]    # thin-channel weight gradients that took the second stream (tests)
+_side_conv_calls = [0]     # the regressor's
+
+
+def _note_use(w):
+    """Forward half of the shared-weight test of the side-stream weight gradients: a weight used twice in one graph has its two
+    gradients SUMMED by autograd on the main stream, so neither may be written on the side stream.  Called by the Python
+    wrappers right before `Function.apply` -- inside `forward` grad mode is always off and says nothing about the caller's
+    (rounds 3-4 counted there, i.e. never: no model of this package shares a convolution weight, so nothing ever raced).
+    `w._hp_uses`: {forward epoch: uses not yet consumed by a backward}; entries older than 8 epochs are dropped (a graph that was
+    built and never differentiated must not keep a weight off the side stream for the rest of the process)."""
+    if torch.is_grad_enabled() and w is not None and w.requires_grad:
+        ep = _use_epoch[0]
+        d = getattr(w, "_hp_uses", None)
+        if not isinstance(d, dict):
+            d = {}
+        for k in [k for k in d if k < ep - 8]:
+            del d[k]
+        d[ep] = d.get(ep, 0) + 1
+        w._hp_uses = d
+
+
+def _shared_use(ctx, w):
+    """Backward half: True if this weight's gradient must stay on the main stream -- it has more than one outstanding use (in
+    this forward or in another one whose graph may be part of the same backward), or this use was never counted (a caller
+    that bypassed the wrappers: nothing is known).  Releases this use; the flag `_hp_shared` keeps the remaining uses of the
+    pass on the main stream as well."""
+    d = getattr(w, "_hp_uses", None)
+    if not isinstance(d, dict):
+        d = {}
+    total, mine = sum(d.values()), d.get(ctx.use_epoch, 0)
+    shared = total > 1 or mine == 0 or getattr(w, "_hp_shared", False)
+    if total > 1:
+        w._hp_shared = True
+    if mine > 0:
+        if mine == 1:
+            del d[ctx.use_epoch]
+        else:
+            d[ctx.use_epoch] = mine - 1
+        if not d:
+            w._hp_shared = False
+    return shared
+
+
 def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0, w_param=None, b_param=None):
     """(dx, dw, db) of y = conv3(x, w) + b given g = dL/dy; planar tensors."""
     L = _lib.lib()
@@ -106,6 +150,7 @@ def _dconv3_grads(x, w, g, replicate, has_bias, need_dx, prec=0, w_param=None, b
         _lib.check(L.hp_dconv3_backward_weight_p(xe.data_ptr(), ge.data_ptr(), dw.data_ptr(), _lib.ptr(db), b, cin, cout,
                                                  d, h, wd, rp, wprec & 1, wsw.data_ptr(), _stream(x)), "hp_dconv3_backward_weight_p")
     _hold(x.device, side, main, (xe, ge, wsw))
+    _side_dconv_calls[0] += 1
     return gx, dw, db
 
 
@@ -135,6 +180,7 @@ class _DConv3(torch.autograd.Function):
         ctx.cfg = (replicate, bias is not None, res is not None, float(slope))
         ctx.prec = _DCONV_PRECISION
         ctx.bias_ref = bias     # (the parameter itself, for the side-stream test of its backward; not a saved tensor: no version check)
+        ctx.use_epoch = _use_epoch[0]
         return y
 
     @staticmethod
@@ -151,7 +197,8 @@ class _DConv3(torch.autograd.Function):
             x, w = ctx.saved_tensors
             g = gy
         with torch.cuda.device(x.device):
-            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0], ctx.prec, w, ctx.bias_ref)
+            gx, dw, db = _dconv3_grads(x, w, g, replicate, has_bias, ctx.needs_input_grad[0], ctx.prec,
+                                       None if _shared_use(ctx, w) else w, ctx.bias_ref)
         return gx, dw, db, None, (g if has_res else None), None
 
 
@@ -191,6 +238,7 @@ class _ConvGnRelu(torch.autograd.Function):
         ctx.cfg = (groups, bias is not None)
         ctx.prec = _DCONV_PRECISION
         ctx.bias_ref = bias
+        ctx.use_epoch = _use_epoch[0]
         return y
 
     @staticmethod
@@ -210,7 +258,8 @@ class _ConvGnRelu(torch.autograd.Function):
                                                        gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), aff[0].data_ptr(),
                                                        aff[1].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                                                        _stream(z)), "hp_groupnorm_relu_backward_v2")
-            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0], ctx.prec, w, ctx.bias_ref)
+            gx, dw, db = _dconv3_grads(x, w, dz, False, has_bias, ctx.needs_input_grad[0], ctx.prec,
+                                       None if _shared_use(ctx, w) else w, ctx.bias_ref)
         return gx, dw, db, dgamma, dbeta, None, None, None
 
 
@@ -218,6 +267,7 @@ class _ConvGnRelu(torch.autograd.Function):
 def conv3d_reppad(x, w, b, stride=1, residual=None, slope=1.0):
     """ReplicationPad3d(1) + Conv3d(3^3) [+ residual] [+ LeakyReLU(slope)] in one kernel."""
     assert stride == 1, "NlosPose uses FeatureExtraction with stride 1 (models/NlosPose.py:20-24)"
+    _note_use(w)
     return _DConv3.apply(x, w, b, True, residual, slope)
 
 
@@ -263,6 +313,7 @@ def feature_extraction_fused(x, fe):
     _need_cuda(x, "feature_extraction")
     a = conv3d_reppad(x, fe.conv1[1].weight, fe.conv1[1].bias)
     a = fe.conv1[3](fe.conv1[2](a))
+    _note_use(fe.weights)
     return _DConv3.apply(x, fe.weights, None, False, a, 1.0)   # box filter branch + learned branch, added in the epilogue
 
 
@@ -539,6 +590,7 @@ def conv3d(x, w, b=None, stride=1, padding=0):
 
 
 def conv3_gn_relu(x, w, b, gw, gb, groups, eps, out=None):
+    _note_use(w)
     return _ConvGnRelu.apply(x, w, b, gw, gb, groups, eps, out)
 
 
@@ -813,7 +865,7 @@ def join_side_streams():
             q.clear()            # everything queued so far is ordered before whatever the main stream does next
 
 
-def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=None):
+def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=None, force_main=False):
     """(dx, dw) of z = conv(x, w) given dz; all channels-last, dw in the torch weight layout.  bn_in: the BnLink of the unit that
     produced x (see there): its BatchNorm-backward sums are taken by the data-gradient kernel where the geometry allows."""
     L = _lib.lib()
@@ -869,7 +921,7 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=No
         # weight used twice in one graph has its two gradients SUMMED by autograd on the main stream: main-stream path.
         hooked = bool(getattr(w, "_backward_hooks", None)) or \
             (bool(getattr(w, "_post_accumulate_grad_hooks", None)) and not (w.is_leaf and w.grad is not None))
-        if (not w.is_leaf) or hooked or getattr(w, "_hp_shared", False):
+        if (not w.is_leaf) or hooked or force_main:
             side = None
     if side is None:
         dwp = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -907,6 +959,7 @@ def _conv_grads(desc, x, w, dz, need_dx, addend=None, addend_mask=None, bn_in=No
     # summed into w.grad above dies with this call and MUST be held: its block was allocated on the main stream.)
     keep = (x, dz, w, dwp, dw) if accumulate else ((x, dz, w) if dw.data_ptr() == dwp.data_ptr() else (x, dz, w, dwp))
     _hold(x.device, side, main, keep)
+    _side_conv_calls[0] += 1
     del dwp, keep
     if accumulate:
         for fn in _side_grad_listeners:   # called with the MAIN stream current: a listener orders itself behind both
@@ -927,10 +980,7 @@ class _ConvBnAct(torch.autograd.Function):
                 bn_in=None, bn_out=None):
         L = _lib.lib()
         x = x.contiguous()
-        ctx.use_epoch = _use_epoch[0]
-        if _WGRAD_ASYNC and torch.is_grad_enabled():
-            e, c = getattr(w, "_hp_uses", (-1, 0))      # a weight used twice in one graph must not take the side stream
-            w._hp_uses = (_use_epoch[0], c + 1 if e == _use_epoch[0] else 1)
+        ctx.use_epoch = _use_epoch[0]   # (the use count of w itself: _note_use() in the wrappers conv_bn_act / deconv_bn_relu)
         cout = w.shape[1] if transposed else w.shape[0]
         desc = _desc(x, cout, k, stride, pad, transposed)
         do, ho, wo = _out_dims(desc)
@@ -1063,18 +1113,9 @@ class _ConvBnAct(torch.autograd.Function):
             last = True
             if link_in is not None and ctx.needs_input_grad[0]:
                 addend, addend_mask, last = link_in.take()
-            e, uses = getattr(w, "_hp_uses", (-1, 0))
-            stale = uses > 0 and e != ctx.use_epoch   # counted by another forward: nothing is known about this graph
-            if uses > 1 or stale:
-                w._hp_shared = True        # every backward of this weight in this pass stays on the main stream
             # (a block input reaches two convolutions: its gradient is complete only in the one that runs last)
-            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask, bn_in=ctx.bn_links[0] if last else None)
-            if stale:
-                w._hp_shared = False
-            elif uses > 0:
-                w._hp_uses = (e, uses - 1)
-                if uses == 1:
-                    w._hp_shared = False
+            dx, dw = _conv_grads(desc, x, w, dz, ctx.needs_input_grad[0], addend, addend_mask, bn_in=ctx.bn_links[0] if last else None,
+                                 force_main=_WGRAD_ASYNC and _shared_use(ctx, w))
             if not last:           # first of two convolutions reading the block input: park the partial sum
                 link_in.g, dx = dx, None
             gres = g
@@ -1157,11 +1198,15 @@ class _MaxPool3CL(torch.autograd.Function):
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, res_link=None, bn_in=None, bn_out=None):
     """x channels-last (B,D,H,W,C).  bn_in / bn_out: BnLinks to the unit that produced x / to the one consumer of the output."""
+    if _WGRAD_ASYNC:
+        _note_use(conv.weight)
     return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.kernel_size[0], conv.stride[0],
                             conv.padding[0], False, relu, link_in, link_out, res_link, bn_in, bn_out)
 
 
 def deconv_bn_relu(x, deconv, bn, bn_in=None, bn_out=None):
+    if _WGRAD_ASYNC:
+        _note_use(deconv.weight)
     return _ConvBnAct.apply(x, deconv.weight, bn.weight, bn.bias, None, bn, 4, 2, 1, True, True, None, None, None, bn_in, bn_out)
 
 

@@ -594,6 +594,40 @@ def test_side_stream_weight_gradient_with_a_tensor_hook_or_shared_weight():
     assert len(s0) == len(s1) and all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(s0, s1))
 
 
+def test_a_convolution_weight_used_twice_in_one_graph_stays_on_the_main_stream():
+    """The shared-weight rule without a hook in play (round 4: the use counts are taken by the wrappers conv_bn_act /
+    deconv_bn_relu, where grad mode is the caller's -- inside Function.forward it is always off, so the counts of rounds 3-4 never
+    counted): the same Conv3d twice in one graph -> autograd SUMS the two weight gradients on the main stream, so neither may be
+    written on the second stream; a weight used once takes it.  Gradients equal the one-stream run."""
+    from torch import nn
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 6, 6, 8, 64, generator=g).cuda()
+    w0 = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).cuda()
+
+    def run(async_on, twice):
+        conv, bn = nn.Conv3d(64, 64, 3, padding=1, bias=False).cuda(), nn.BatchNorm3d(64).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(w0)
+        prev = ops.set_wgrad_async(async_on)
+        n0 = ops._side_conv_calls[0]
+        try:
+            y = ops.conv_bn_act(x, conv, bn)
+            if twice:
+                y = ops.conv_bn_act(y, conv, bn)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_wgrad_async(prev)
+        assert not getattr(conv.weight, "_hp_uses", {}) and not getattr(conv.weight, "_hp_shared", False)
+        return conv.weight.grad.clone(), ops._side_conv_calls[0] - n0
+
+    for twice in (True, False):
+        (g1, n1), (g0, n0_) = run(True, twice), run(False, twice)
+        assert n0_ == 0 and n1 == (0 if twice else 1), (twice, n1, n0_)
+        assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("ca,cb,kb,transposed,dims", [
     (64, 64, 3, False, (2, 4, 8, 8)),      # conv1 -> conv2 of a Bottleneck: 64-column tile, 3^3 consumer
     (64, 256, 1, False, (2, 4, 8, 8)),     # conv2 -> conv3: 64-column tile, 1^3 consumer

@@ -195,7 +195,7 @@ def test_thin_channel_weight_gradients_on_the_second_stream_equal_the_serial_one
                 ps[4].grad = torch.full_like(ps[4], 0.5)
             xi = x.clone().requires_grad_(True)
             for _ in range(2):          # twice: the hold queue and the end-of-backward join are exercised across passes
-                y = ops._DConv3.apply(ops.conv3_gn_relu(xi, ps[0], ps[1], ps[2], ps[3], 4, 1e-5), ps[4], ps[5], False, xi, 0.2)
+                y = ops.conv3d_reppad(ops.conv3_gn_relu(xi, ps[0], ps[1], ps[2], ps[3], 4, 1e-5), ps[4], ps[5], residual=xi, slope=0.2)
                 (y * gy).sum().backward()
             torch.cuda.synchronize()
             return [xi.grad.clone()] + [p.grad.clone() for p in ps]
@@ -203,6 +203,46 @@ def test_thin_channel_weight_gradients_on_the_second_stream_equal_the_serial_one
             ops._DCONV_WGRAD_STREAM = prev
 
     for pre in (False, True):
-        a, b = run(True, pre), run(False, pre)
+        n0 = ops._side_dconv_calls[0]
+        a = run(True, pre)
+        n1 = ops._side_dconv_calls[0]
+        b = run(False, pre)
+        # first pass: both layers (or the one without an accumulated gradient) take the second stream; second pass: none does
+        assert n1 - n0 == (1 if pre else 2) and ops._side_dconv_calls[0] == n1
         for u, v in zip(a, b):
             assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_a_thin_channel_weight_used_twice_stays_on_the_main_stream():
+    """A weight that appears twice in one graph has its two gradients SUMMED by autograd on the main stream: neither may be written
+    on the second stream (hip_ops._count_use / _shared_use, as for the regressor's convolutions).  Bit-equal to the one-stream run,
+    over two passes (the use counts return to zero)."""
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(1, 4, 10, 16, 64, generator=g).cuda()
+    w0 = (torch.randn(4, 4, 3, 3, 3, generator=g) * 0.2).cuda()
+    b0 = torch.randn(4, generator=g).cuda()
+    gy = torch.randn(1, 4, 10, 16, 64, generator=g).cuda()
+
+    def run(on):
+        prev = ops._DCONV_WGRAD_STREAM
+        ops._DCONV_WGRAD_STREAM = on
+        try:
+            out = []
+            for _ in range(2):
+                w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+                xi = x.clone().requires_grad_(True)
+                y = ops.conv3d_reppad(ops.conv3d_reppad(xi, w, b, slope=0.2), w, b, residual=xi)
+                (y * gy).sum().backward()
+                torch.cuda.synchronize()
+                assert not getattr(w, "_hp_uses", {}) and not getattr(w, "_hp_shared", False)   # every use consumed
+                out += [xi.grad.clone(), w.grad.clone(), b.grad.clone()]
+            return out
+        finally:
+            ops._DCONV_WGRAD_STREAM = prev
+
+    n0 = ops._side_dconv_calls[0]
+    a = run(True)
+    assert ops._side_dconv_calls[0] == n0       # the shared weight never took the second stream
+    for u, v in zip(a, run(False)):
+        assert torch.equal(u, v)
